@@ -1,0 +1,111 @@
+"""Known-answer tests pinning the oracle's restatement of the tiny-cuda-nn hash
+grid (parity vs tiny-cuda-nn itself is unpinned)."""
+import numpy as np
+import torch
+
+from oracle import immoco_oracle as orc
+
+
+def test_level_geometry_2d_3d():
+    g2 = orc.geometry_from_config(2, orc.encoding_config)
+    assert g2.resolutions[:7] == [16, 32, 64, 128, 256, 512, 1024]
+    assert g2.sizes[:6] == [256, 1024, 4096, 16384, 65536, 262144] and set(g2.sizes[6:]) == {524288}
+    assert g2.offsets[:7] == [0, 256, 1280, 5376, 21760, 87296, 349440]
+    assert g2.hashed == [False] * 6 + [True] * 10
+    assert g2.n_entries == 5592320
+    g3 = orc.geometry_from_config(3, orc.encoding_config)
+    assert g3.sizes[:3] == [4096, 32768, 262144] and g3.offsets[:4] == [0, 4096, 36864, 299008]
+    assert g3.hashed == [False] * 3 + [True] * 13
+    assert g3.n_entries == 7114752
+    assert [s for s in g3.scales[:3]] == [15.0, 31.0, 63.0]
+    # parameter counts quoted in SURVEY a5/a6
+    m_img = orc.mlp_spec_from_config(32, 2, orc.network_config)
+    m_mot = orc.mlp_spec_from_config(32, 2, orc.mot_network_config)
+    assert m_img.n_params + g2.n_table_params == 11194880
+    assert m_mot.n_params + g3.n_table_params == 14232576
+
+
+def test_hash_known_answers():
+    g3 = orc.geometry_from_config(3, orc.encoding_config)
+    cell = np.array([[1, 2, 3], [0, 0, 0], [0xFFFFFFFF, 5, 7]], dtype=np.uint64)
+    lvl = 5
+    assert g3.hashed[lvl]
+    exp = []
+    for c in cell.tolist():
+        h = 0
+        for d in range(3):
+            h ^= (c[d] * orc.PRIMES[d]) & 0xFFFFFFFF
+        exp.append(h % 524288)
+    assert orc.grid_index(cell, g3, lvl).tolist() == exp
+    assert exp[0] == ((1 ^ ((2 * 2654435761) & 0xFFFFFFFF) ^ ((3 * 805459861) & 0xFFFFFFFF)) % 524288)
+
+
+def test_dense_index_negative_wrap():
+    """x in [-1,0) gives negative cells that wrap mod 2^32."""
+    g2 = orc.geometry_from_config(2, orc.encoding_config)
+    coords = np.array([[-1.0, -1.0], [1.0, 1.0], [-0.5, 0.25]], dtype=np.float32)
+    cell, frac = orc.grid_cells(coords, g2, 0)          # scale 15: pos = 15x+0.5
+    assert cell[0].tolist() == [0xFFFFFFF1, 0xFFFFFFF1] and np.allclose(frac[0], 0.5)
+    assert cell[1].tolist() == [15, 15]
+    assert cell[2].tolist() == [0xFFFFFFF9, 4]            # floor(-7.0)=-7 ; floor(4.25)=4
+    idx = orc.grid_index(cell, g2, 0)
+    assert idx[0] == ((0xFFFFFFF1 + 0xFFFFFFF1 * 16) & 0xFFFFFFFF) % 256
+    assert idx[1] == (15 + 15 * 16) % 256
+
+
+def test_interpolation_weights_and_linearity():
+    g = torch.Generator().manual_seed(0)
+    coords = (torch.rand(257, 3, generator=g) * 2 - 1)
+    g3 = orc.geometry_from_config(3, orc.encoding_config)
+    plan = orc.HashGridPlan(coords, g3)
+    assert plan.idx.shape == (257, 16, 8)
+    np.testing.assert_allclose(plan.w.sum(-1).numpy(), 1.0, atol=1e-6)
+    for l in range(16):
+        assert int(plan.idx[:, l].min()) >= g3.offsets[l] and int(plan.idx[:, l].max()) < g3.offsets[l + 1]
+    # a constant table encodes to that constant
+    tab = torch.ones(g3.n_entries, 2) * torch.tensor([0.25, -2.0])
+    enc = plan.encode(tab).view(257, 16, 2)
+    np.testing.assert_allclose(enc[..., 0].numpy(), 0.25, rtol=1e-6)
+    np.testing.assert_allclose(enc[..., 1].numpy(), -2.0, rtol=1e-6)
+
+
+def test_inr_gradient_vs_float64_finite_difference():
+    """fp32 autograd gradient of the oracle INR == float64 central differences."""
+    torch.manual_seed(0)
+    inr = orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, seed=5)
+    x = orc.make_grids((6, 5))
+    tgt = torch.randn(30, 2)
+    plan = inr.plan_for(x)
+
+    def f64(p):
+        w1, w2, tab = inr.split(p)
+        h = torch.relu(plan.encode(tab) @ w1.t())
+        return (((h @ w2.t())[:, :2] - tgt.double()) ** 2).sum()
+
+    loss = ((inr(x) - tgt) ** 2).sum()
+    loss.backward()
+    g = inr.params.grad.clone()
+    p64 = inr.params.detach().double()
+    idx = torch.cat([torch.arange(0, 4), torch.arange(inr.mlp.n_w1, inr.mlp.n_w1 + 4),
+                     g[inr.mlp.n_params:].abs().topk(6).indices + inr.mlp.n_params])
+    for i in idx.tolist():
+        eps = 1e-7
+        pp, pm = p64.clone(), p64.clone()
+        pp[i] += eps
+        pm[i] -= eps
+        fd = float((f64(pp) - f64(pm)) / (2 * eps))
+        assert abs(fd - g[i].item()) <= 2e-3 * abs(fd) + 1e-9, (i, fd, g[i].item())
+
+
+def test_init_distribution():
+    g2 = orc.geometry_from_config(2, orc.encoding_config)
+    m = orc.mlp_spec_from_config(32, 2, orc.network_config)
+    p = orc.init_inr_params(g2, m, 1337)
+    assert p.shape == (11194880,) and p.dtype == np.float32
+    b1 = np.sqrt(6 / (32 + 256))
+    assert np.abs(p[: m.n_w1]).max() <= b1 and np.abs(p[: m.n_w1]).max() > 0.98 * b1
+    t = p[m.n_params:]
+    assert np.abs(t).max() <= 1e-4 and abs(t.mean()) < 1e-7 and abs(t.std() - 1e-4 / np.sqrt(3)) < 1e-7
+    # different seeds / streams decorrelate
+    q = orc.init_inr_params(g2, m, 1338)
+    assert abs(np.corrcoef(p[:8192], q[:8192])[0, 1]) < 0.05
