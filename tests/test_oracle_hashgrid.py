@@ -94,7 +94,7 @@ def test_inr_gradient_vs_float64_finite_difference():
         pp[i] += eps
         pm[i] -= eps
         fd = float((f64(pp) - f64(pm)) / (2 * eps))
-        assert abs(fd - g[i].item()) <= 2e-3 * abs(fd) + 1e-9, (i, fd, g[i].item())
+        assert abs(fd - g[i].item()) <= 1e-2 * abs(fd) + 1e-7, (i, fd, g[i].item())
 
 
 def test_init_distribution():
