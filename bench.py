@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — IM-MoCo per-slice inner optimisation loop on MI355X.
+
+Metric (BASELINE.json): slices/s at 320x320, 10 motion groups, 3000 Adam iterations
+(config C2).  A "step" is one full slice solve (immoco.py:116-206: normalisation, INR
+init, 3000 iterations, last-forward outputs); inputs are synthetic (seeded phantom +
+the reference's motion simulator) and resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W [--iters 3000] [--no-cpu-baseline]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank solves its own
+K slices (weak scaling, no data-path collective); the only collective is the final
+gather of the images (outside the hot loop, inside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 320
+N_MOVEMENTS = 10
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(solver, nM):
+    """Algorithmic HBM bytes per launch of each kernel of the iteration:
+    compulsory reads/writes of the tensors the kernel consumes/produces, tables counted once."""
+    P = H * W
+    NP = nM * P
+    npi, npm = solver.n_params_image, solver.n_params_motion
+    tab_i, tab_m = 4 * (npi - 256 * 40), 4 * (npm - 64 * 48)
+    return {
+        "image_encode_fwd": tab_i + 128 * P,
+        "image_mlp_fwd": 128 * P + 8 * P,
+        "image_to_fft_slot": 16 * P,
+        "motion_encode_fwd": tab_m + 128 * NP,
+        "motion_mlp_fwd": 128 * NP + 8 * NP,
+        "motion_warp_fwd": 8 * NP + 8 * P + 16 * NP,
+        "fft_fwd": 16 * (nM + 1) * P,
+        "select_dc_seed": 8 * P * 3 + 8 * (nM + 1) * P,
+        "fft_adjoint": 16 * (nM + 1) * P,
+        "image_grad_init_ge": 24 * P,
+        "motion_warp_bwd": 8 * NP * 3 + 16 * P,
+        "motion_mlp_bwd": 128 * NP * 2 + 8 * NP,
+        "motion_encode_bwd": 128 * NP + 2 * tab_m,
+        "image_mlp_bwd": 128 * P * 2 + 8 * P,
+        "image_encode_bwd": 128 * P + 2 * tab_i,
+        "adam_motion": 28 * npm,
+        "adam_image": 28 * npi,
+        "tick": 4,
+    }
+
+
+def cpu_baseline(iters_sample=2):
+    """The oracle (CPU restatement of the reference loop) on this box's host cores, config C2,
+    a bounded sample of iterations; slices/s extrapolated to 3000 iterations."""
+    from oracle import immoco_oracle as orc
+    from miccai24_immoco_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    s = synth.make_slice(H, W, N_MOVEMENTS, 0)
+    masks = orc.extract_movement_groups(s["lines"], make_list=True)
+    model = orc.OracleIMMoCo(masks)
+    k = s["kspace"]
+    kin = k.div(k.abs().max()).mul(16000)
+    opt = torch.optim.Adam([{"params": model.motion_inr.parameters(), "lr": 1e-2},
+                            {"params": model.image_inr.parameters(), "lr": 1e-2}])
+    import torch.nn.functional as F
+
+    def one():
+        opt.zero_grad()
+        kf, ip = model()
+        loss = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(kin)) + orc.gradient_entropy_loss(ip) * 1e-2
+        loss.backward()
+        opt.step()
+    one()  # builds the coordinate plans (not timed: constant per shape)
+    t0 = time.perf_counter()
+    for _ in range(iters_sample):
+        one()
+    dt = (time.perf_counter() - t0) / iters_sample
+    return {"value": 1.0 / (3000 * dt), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{iters_sample} Adam iterations of config C2 (320x320, {masks.shape[0]} groups) with the torch-CPU "
+                      f"oracle, {dt:.2f} s/iter, extrapolated x3000 iterations"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=3000, help="Adam iterations per slice (BASELINE: 3000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import miccai24_immoco_amd as pkg
+    from miccai24_immoco_amd import _lib, synth
+    from miccai24_immoco_amd.models.immoco import get_solver, lambda_schedule
+    from miccai24_immoco_amd.shard import gather_images
+    _lib.lib()   # fail loudly without the HIP library
+
+    K, Wm = args.steps, args.warmup
+    # ---- synthetic inputs, resident in HBM before the timed region ---------------------------
+    slices = []
+    for j in range(Wm + K):
+        gidx = rank * (Wm + K) + j
+        s = synth.make_slice(H, W, N_MOVEMENTS, gidx)
+        masks = pkg.extract_movement_groups(s["lines"].to(dev), make_list=True)
+        slices.append({"kspace": s["kspace"].to(dev), "masks": masks, "gt": s["gt"]})
+    nM = int(slices[0]["masks"].shape[0])
+    get_solver(dev, H, W, nM, not args.no_graph)      # plans + workspace (one-off, like FFT plan creation)
+
+    def solve(sl):
+        return pkg.imcoco_motion_correction(sl["kspace"], sl["masks"], iters=args.iters, learning_rate=1e-2,
+                                            lambda_ge=1e-2, use_graph=not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for j in range(Wm):
+        solve(slices[j])
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    imgs = [solve(slices[Wm + j])[0] for j in range(K)]
+    local = torch.stack(imgs)
+    allimgs = gather_images(local, K * world)          # the single RCCL collective (final images)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = K * world / dt
+    ms_per_step = dt / K * 1e3
+
+    out = None
+    if rank == 0:
+        from miccai24_immoco_amd.utils.evaluate import crop_psnr
+        psnr = [crop_psnr(imgs[j].abs().cpu(), slices[Wm + j]["gt"].abs()) for j in range(K)]
+        from miccai24_immoco_amd.utils.data_utils import IFFT
+        psnr_in = [crop_psnr(IFFT(slices[Wm + j]["kspace"]).abs().cpu(), slices[Wm + j]["gt"].abs()) for j in range(K)]
+        # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
+        solver = get_solver(dev, H, W, nM, not args.no_graph)
+        sl = slices[0]
+        k = sl["kspace"]
+        kin = k / k.abs().max() * 16000
+        from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+        cg = masks_to_col_group(sl["masks"])
+        pi, pm = solver.init_params()
+        ai = torch.zeros(2 * pi.numel(), device=dev)
+        am = torch.zeros(2 * pm.numel(), device=dev)
+        solver.profile(kin, cg, pi, pm, ai, am, reps=3)            # warm
+        phases = solver.profile(kin, cg, pi, pm, ai, am, reps=10)
+        ab = algorithmic_bytes(solver, nM)
+        t_iter_ms = sum(ms for _, ms in phases)
+        name, ms = max(phases, key=lambda p: p[1])
+        achieved = ab[name] / (ms * 1e-3) / 1e9
+        b_iter = 28 * (solver.n_params_image + solver.n_params_motion) + 8 * H * W
+        iter_ms_graph = ms_per_step / args.iters
+        roofline = {
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None,
+            "kernel_ms": round(ms, 4), "kernel_algorithmic_bytes": ab[name],
+            "iteration": {"algorithmic_bytes": b_iter, "ms_graph": round(iter_ms_graph, 4),
+                          "ms_sum_of_kernels_eager": round(t_iter_ms, 4),
+                          "achieved_GBs": round(b_iter / (iter_ms_graph * 1e-3) / 1e9, 2),
+                          "frac": round(b_iter / (iter_ms_graph * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
+            "kernels_ms": {n: round(m, 4) for n, m in phases},
+        }
+        out = {
+            "metric": "slices/sec at 320x320, 10 motion groups, 3000 iters; PSNR delta vs ref",
+            "value": round(value, 5), "unit": "slices/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: single 320x320 slice, 10 motion groups, 3000 Adam iters, hash-grid INRs",
+                       "H": H, "W": W, "motion_groups": nM, "iters": args.iters, "slices_per_gpu": K,
+                       "graph": bool(solver.graph_active), "parallelism": f"slices sharded over {world} GPU(s)"},
+            "psnr_db": {"solved": [round(p, 3) for p in psnr], "corrupted_input": [round(p, 3) for p in psnr_in]},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

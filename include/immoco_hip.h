@@ -1,0 +1,210 @@
+/*
+ * immoco_hip.h — C-ABI of the MI355X-native IM-MoCo inner-loop library
+ * (libimmoco_hip.so, built from miccai24_immoco_amd/csrc for gfx950).
+ *
+ * The reference (multimodallearning/MICCAI24_IMMoCo) is pure Python and has no
+ * FFI of its own; the native code it reaches on this path is tiny-cuda-nn's
+ * torch binding, ATen (grid_sample, foreach Adam) and cuFFT.  Each entry point
+ * below names the reference interface (file:line under /root/reference) it
+ * replaces.  Conventions:
+ *   - plain pointers and sizes only; every buffer is a caller-allocated DEVICE
+ *     pointer unless marked [host];
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are
+ *     asynchronous on that stream unless stated otherwise;
+ *   - return 0 on success, negative on error (IMMOCO_E_*), message via
+ *     immoco_last_error(); no exceptions cross the ABI;
+ *   - complex data is interleaved float (re, im), i.e. torch.complex64 memory;
+ *   - "accumulates" means the kernel ADDS into the output (caller zeroes it).
+ */
+#ifndef IMMOCO_HIP_H
+#define IMMOCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMMOCO_OK 0
+#define IMMOCO_E_INVALID (-1) /* bad argument / unsupported configuration */
+#define IMMOCO_E_HIP (-2)     /* HIP runtime error                         */
+#define IMMOCO_E_FFT (-3)     /* rocFFT/hipFFT error                       */
+
+#define IMMOCO_MAX_LEVELS 16
+#define IMMOCO_ACT_RELU 0
+#define IMMOCO_ACT_TANH 1
+
+/* tiny-cuda-nn "Grid"/"Hash"/"Linear" encoding config (immoco.py:27-37). */
+typedef struct immoco_grid_cfg {
+  int32_t dims;               /* 2 (image INR, immoco.py:60) or 3 (motion INR, :63) */
+  int32_t n_levels;           /* <= IMMOCO_MAX_LEVELS */
+  int32_t n_features;         /* must be 2 */
+  int32_t log2_hashmap_size;
+  int32_t base_resolution;
+  float per_level_scale;
+} immoco_grid_cfg;
+
+/* Derived level geometry (tiny-cuda-nn grid.h). [host] */
+typedef struct immoco_grid_geometry {
+  uint32_t offset[IMMOCO_MAX_LEVELS + 1]; /* entry offsets, [n_levels] = total entries */
+  uint32_t resolution[IMMOCO_MAX_LEVELS];
+  uint32_t size[IMMOCO_MAX_LEVELS];
+  float scale[IMMOCO_MAX_LEVELS];
+  uint8_t hashed[IMMOCO_MAX_LEVELS];
+} immoco_grid_geometry;
+
+/* tiny-cuda-nn MLP config with one hidden layer, no biases (immoco.py:11-25). */
+typedef struct immoco_mlp_cfg {
+  int32_t n_in;         /* 32 = n_levels * n_features */
+  int32_t n_hidden;     /* 256 (image) or 64 (motion) */
+  int32_t n_out;        /* 2 */
+  int32_t n_out_padded; /* 8 (CutlassMLP) or 16 (FullyFusedMLP) rows stored in W2 */
+  int32_t activation;   /* IMMOCO_ACT_* */
+} immoco_mlp_cfg;
+
+/* ---- library ------------------------------------------------------------ */
+int immoco_version(void);
+/* Copies the calling thread's last error message into buf (NUL terminated). */
+int immoco_last_error(char* buf, size_t n);
+
+/* ---- INR: hash grid (replaces tinycudann.NetworkWithInputEncoding's encoding,
+ *      immoco.py:60-65,85,93) --------------------------------------------- */
+int immoco_grid_geometry_query(const immoco_grid_cfg* cfg, immoco_grid_geometry* out /*[host]*/);
+/* enc[p*enc_point_stride + l*enc_level_stride + f] for p<n, l<n_levels, f<2.
+ * tcnn layout [n,32]: point_stride=32, level_stride=2; solver layout [L][n][2]:
+ * point_stride=2, level_stride=2n.  table: [n_entries][2] fp32. */
+int immoco_hashgrid_fwd(const immoco_grid_cfg* cfg, const float* coords /*[n,dims]*/, int64_t n,
+                        const float* table, float* enc, int64_t enc_point_stride,
+                        int64_t enc_level_stride, void* stream);
+/* Accumulates dtable[n_entries][2] += scatter(denc) (same strides as fwd). */
+int immoco_hashgrid_bwd(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
+                        const float* denc, int64_t enc_point_stride, int64_t enc_level_stride,
+                        float* dtable, void* stream);
+
+/* ---- INR: bias-free one-hidden-layer MLP (tcnn CutlassMLP / FullyFusedMLP) */
+/* w1 [n_hidden][n_in], w2 [n_out_padded][n_hidden] row-major; out [n][n_out]. */
+int immoco_mlp_fwd(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                   int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                   float* out, void* stream);
+/* din written (same strides as in); dw1/dw2 ACCUMULATE (padded rows of dw2 untouched). */
+int immoco_mlp_bwd(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                   int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                   const float* dout /*[n][n_out]*/, float* din, float* dw1, float* dw2,
+                   void* stream);
+
+/* ---- parameter init (tcnn: encoding U(-1e-4,1e-4), MLP Xavier-uniform on the
+ *      padded shapes; counter-based generator shared bit-exactly with the oracle) */
+int immoco_init_params(const immoco_grid_cfg* grid, const immoco_mlp_cfg* mlp, uint32_t seed,
+                       float* params /*[n_w1 + n_w2 + 2*n_entries]*/, void* stream);
+
+/* ---- warp: F.grid_sample(bilinear, zeros, align_corners=False) of ONE complex
+ *      image at nM sampling grids (immoco.py:91,97-107) -------------------- */
+int immoco_warp_fwd(const float* image /*[H,W] c64*/, const float* grids /*[nM,H,W,2] (x,y)*/,
+                    int32_t nM, int32_t H, int32_t W, float* out /*[nM,H,W] c64*/, void* stream);
+/* dimage ACCUMULATES; dgrids written. */
+int immoco_warp_bwd(const float* image, const float* grids, const float* dout, int32_t nM,
+                    int32_t H, int32_t W, float* dimage, float* dgrids, void* stream);
+
+/* ---- centred FFTs (src/utils/data_utils.py:29-34) over the last two dims.
+ * mode 0: FFT  = fftshift(fftn(ifftshift(x)))   unnormalised
+ * mode 1: IFFT = ifftshift(ifftn(fftshift(x)))  1/(HW)
+ * mode 2: adjoint of mode 0 (= HW * IFFT), used by the backward pass.
+ * in may equal out.  Plans are cached per (batch,H,W) inside the library. */
+int immoco_fft2c(const float* in, float* out, int32_t batch, int32_t H, int32_t W, int32_t mode,
+                 void* stream);
+
+/* ---- k-space line select (immoco.py:109-111) and losses ------------------ */
+/* kout[r,c] = kall[col_group[c]][r,c]; kall [(nM+1),H,W] c64, slot 0 = FFT(image). */
+int immoco_kspace_select(const float* kall, const int32_t* col_group /*[W]*/, int32_t nM, int32_t H,
+                         int32_t W, float* kout, void* stream);
+/* F.mse_loss(view_as_real(k), view_as_real(kin)) (immoco.py:170): loss[0] ACCUMULATES
+ * sum|k-kin|^2/(2HW); dk = (k-kin)/(HW) written if non-NULL. */
+int immoco_dc_loss(const float* k, const float* kin, int32_t H, int32_t W, float* loss, float* dk,
+                   void* stream);
+/* GradientEntropyLoss (src/utils/losses.py:20-40): loss[0] ACCUMULATES weight*GE(x);
+ * dimage (if non-NULL) ACCUMULATES weight*dGE/dx. */
+int immoco_ge_loss(const float* image, int32_t H, int32_t W, float weight, float* loss, float* dimage,
+                   void* stream);
+
+/* ---- torch.optim.Adam step, betas/eps/no-wd defaults (immoco.py:149-154,175) */
+int immoco_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, int32_t step /*1-based*/, void* stream);
+
+/* ---- line-select masks (src/utils/motion_utils.py:56-109), bit-exact ------ */
+/* lines [n] uint8 (0/1) -> col_group [n] int32 (0 = uncorrupted, g>=1 run index);
+ * n_groups[0] (device int32) = number of runs. */
+int immoco_extract_movement_groups(const uint8_t* lines, int32_t n, int32_t* col_group,
+                                   int32_t* n_groups, void* stream);
+/* make_list=False: groups [rows,n] int64 = col_group broadcast down rows. */
+int immoco_groups_to_matrix(const int32_t* col_group, int32_t rows, int32_t n, int64_t* groups,
+                            void* stream);
+/* make_list=True: masks [n_groups,rows,n] int64 one-hot. */
+int immoco_groups_to_masks(const int32_t* col_group, int32_t n_groups, int32_t rows, int32_t n,
+                           int64_t* masks, void* stream);
+/* inverse: masks [nM,rows,n] int64 (row 0 is read) -> col_group [n]. */
+int immoco_masks_to_groups(const int64_t* masks, int32_t nM, int32_t rows, int32_t n,
+                           int32_t* col_group, void* stream);
+
+/* ---- k-space normalisation (immoco.py:137-141): out = k / max|k| * target;
+ *      scale_out[0] (device float) = max|k|. */
+int immoco_normalize_kspace(const float* k, int64_t n_complex, float target, float* out,
+                            float* scale_out, void* stream);
+
+/* ---- fused per-slice solver = imcoco_motion_correction (immoco.py:116-206) */
+typedef struct immoco_solver_cfg {
+  int32_t H, W, nM;
+  immoco_grid_cfg image_grid, motion_grid;
+  immoco_mlp_cfg image_mlp, motion_mlp;
+  int32_t use_graph; /* 1: capture one iteration in a hipGraph and replay it */
+  int32_t reserved[7];
+} immoco_solver_cfg;
+
+typedef struct immoco_solver* immoco_solver_t;
+
+/* Creates plans and the internal workspace (hipMalloc; synchronous). */
+int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_t* out);
+int immoco_solver_destroy(immoco_solver_t s);
+/* Bytes of device memory held by the solver (params/Adam state excluded). */
+int64_t immoco_solver_workspace_bytes(immoco_solver_t s);
+int64_t immoco_solver_n_params(immoco_solver_t s, int32_t which /*0 image, 1 motion*/);
+
+/* Runs `iters` Adam iterations (immoco.py:164-181) on one slice.
+ *  kspace_in  [H,W] c64, ALREADY normalised (immoco_normalize_kspace);
+ *  col_group  [W] int32 (0 = FFT(image) column, m>=1 = FFT(warp_m) column);
+ *  axis coords: xs[W], ys[H], ms[nM] fp32 = the reference's linspace(-1,1,.)
+ *               lattices (immoco.py:48-53,72-80), computed by the caller;
+ *  params_*   flat fp32 [W1|W2|table] (tcnn order), updated in place;
+ *  adam_*     [2*n_params] fp32 (m then v), caller-zeroed for a fresh solve;
+ *  lambda_sched [host][iters] GE weight used at iteration j (immoco.py:180-181);
+ *  out_image / out_kspace [H,W] c64: tensors of the LAST forward pass, i.e.
+ *               before the final Adam step (immoco.py:203-206);
+ *  loss_hist  device [iters] fp32 or NULL: total loss per iteration. */
+int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
+                        const float* xs, const float* ys, const float* ms, float* params_image,
+                        float* params_motion, float* adam_image, float* adam_motion, int32_t iters,
+                        float lr, const float* lambda_sched /*[host]*/, int32_t step0,
+                        float* out_image, float* out_kspace, float* loss_hist, void* stream);
+
+/* One forward pass only (IMMoCo.forward, immoco.py:82-113). */
+int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* xs,
+                          const float* ys, const float* ms, const float* params_image,
+                          const float* params_motion, float* out_image, float* out_kspace,
+                          void* stream);
+
+/* Times every kernel of the iteration with HIP events on the solver's stream:
+ * `reps` eager iterations (parameters / Adam state advance as in a real solve). */
+int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
+                          const float* xs, const float* ys, const float* ms, float* params_image,
+                          float* params_motion, float* adam_image, float* adam_motion, int32_t reps,
+                          float lr, float lambda_ge, void* stream);
+/* Average per-kernel device time (ms) of the last immoco_solver_profile call, for
+ * bench.py's roofline line.  names: [host] array of const char*; returns count. */
+int immoco_solver_phase_times(immoco_solver_t s, const char** names, float* ms, int32_t max_n);
+/* 1 when the last solve replayed a captured hipGraph, 0 when it launched eagerly. */
+int immoco_solver_graph_active(immoco_solver_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMMOCO_HIP_H */

@@ -1,0 +1,261 @@
+// Multiresolution hash-grid encoding, forward and backward (tiny-cuda-nn grid.h
+// semantics restated from SURVEY Appendix A; replaces the encoding half of
+// tinycudann.NetworkWithInputEncoding, reference src/models/immoco.py:60-65,85,93).
+//
+// Layout: one thread per (point, level); blockIdx.y = level, so that all
+// workgroups in flight touch one or two 4 MB level slices of the table, which
+// stay resident in every XCD's 4 MB L2.  Coordinates either come from a generic
+// [n, D] array (op-level API) or from per-axis lattices (solver: the reference
+// always samples linspace(-1,1,.) lattices, immoco.py:48-53,72-80).
+#include "kernels.hpp"
+
+namespace immoco {
+
+int build_levels(const immoco_grid_cfg* cfg, Levels* out) {
+  IMMOCO_REQUIRE(cfg != nullptr, "grid cfg is NULL");
+  IMMOCO_REQUIRE(cfg->dims == 2 || cfg->dims == 3, "grid dims must be 2 or 3 (got %d)", cfg->dims);
+  IMMOCO_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= IMMOCO_MAX_LEVELS, "n_levels %d out of range",
+                 cfg->n_levels);
+  IMMOCO_REQUIRE(cfg->n_features == 2, "n_features_per_level must be 2 (got %d)", cfg->n_features);
+  IMMOCO_REQUIRE(cfg->log2_hashmap_size >= 3 && cfg->log2_hashmap_size <= 28, "log2_hashmap_size %d",
+                 cfg->log2_hashmap_size);
+  IMMOCO_REQUIRE(cfg->base_resolution >= 1 && cfg->per_level_scale >= 1.0f, "bad resolution config");
+  memset(out, 0, sizeof(*out));
+  out->n_levels = cfg->n_levels;
+  out->dims = cfg->dims;
+  const float log2_pls = log2f(cfg->per_level_scale);
+  uint64_t off = 0;
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    // grid_scale(): exp2f(level * log2_per_level_scale) * base_resolution - 1
+    float scale = exp2f((float)l * log2_pls) * (float)cfg->base_resolution - 1.0f;
+    uint32_t res = (uint32_t)ceilf(scale) + 1u;  // grid_resolution()
+    double dense = pow((double)res, cfg->dims);
+    uint64_t n = dense > (double)0x7FFFFFFFu ? 0x7FFFFFFFull : (uint64_t)dense;
+    n = (n + 7) / 8 * 8;
+    uint64_t cap = 1ull << cfg->log2_hashmap_size;
+    if (n > cap) n = cap;
+    uint64_t stride = 1;  // grid_index(): stride after the dense walk
+    for (int d = 0; d < cfg->dims; ++d) {
+      if (stride > n) break;
+      stride *= res;
+    }
+    out->scale[l] = scale;
+    out->res[l] = res;
+    out->size[l] = (uint32_t)n;
+    out->offset[l] = (uint32_t)off;
+    if (n < stride) out->hashed |= 1u << l;
+    if ((n & (n - 1)) == 0) out->pow2 |= 1u << l;
+    off += n;
+    IMMOCO_REQUIRE(off < 0x7FFFFFFFull, "hash table too large");
+  }
+  out->offset[cfg->n_levels] = (uint32_t)off;
+  return IMMOCO_OK;
+}
+
+// ---------------------------------------------------------------------------
+template <int D, bool LAT>
+__device__ __forceinline__ void load_coords(const float* __restrict__ coords, const Lattice& lat,
+                                            int64_t p, float (&x)[D]) {
+  if (LAT) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      int32_t i = (int32_t)((p / lat.stride[d]) % lat.n[d]);
+      x[d] = lat.axis[d][i];
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = coords[p * D + d];
+  }
+}
+
+template <int D, bool LAT>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const float* __restrict__ coords,
+                                                           Lattice lat, int64_t n,
+                                                           const float2* __restrict__ table,
+                                                           float* __restrict__ enc, int64_t ps, int64_t ls) {
+  const int l = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  float x[D];
+  load_coords<D, LAT>(coords, lat, p, x);
+  const float scale = lv.scale[l];
+  const uint32_t size = lv.size[l], res = lv.res[l];
+  const bool hashed = (lv.hashed >> l) & 1u, pow2 = (lv.pow2 >> l) & 1u;
+  const float2* __restrict__ tab = table + lv.offset[l];
+  uint32_t cell[D];
+  float fr[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) pos_fract(x[d], scale, cell[d], fr[d]);
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    uint32_t c[D];
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const bool hi = (corner >> d) & 1;
+      c[d] = cell[d] + (hi ? 1u : 0u);
+      w = __fmul_rn(w, hi ? fr[d] : __fsub_rn(1.0f, fr[d]));
+    }
+    const float2 v = tab[grid_index<D>(c, size, res, hashed, pow2)];
+    // separate mul/add (no contraction): bit-identical to the fp32 oracle
+    const float t0 = __fmul_rn(v.x, w), t1 = __fmul_rn(v.y, w);
+    a0 = corner == 0 ? t0 : __fadd_rn(a0, t0);
+    a1 = corner == 0 ? t1 : __fadd_rn(a1, t1);
+  }
+  *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = make_float2(a0, a1);
+}
+
+// v1 backward: one float atomic per (corner, feature).
+template <int D, bool LAT>
+__global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(Levels lv, const float* __restrict__ coords,
+                                                                  Lattice lat, int64_t n,
+                                                                  const float* __restrict__ denc, int64_t ps,
+                                                                  int64_t ls, float* __restrict__ dtable) {
+  const int l = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float2 g = *reinterpret_cast<const float2*>(denc + p * ps + (int64_t)l * ls);
+  if (g.x == 0.f && g.y == 0.f) return;
+  float x[D];
+  load_coords<D, LAT>(coords, lat, p, x);
+  const float scale = lv.scale[l];
+  const uint32_t size = lv.size[l], res = lv.res[l];
+  const bool hashed = (lv.hashed >> l) & 1u, pow2 = (lv.pow2 >> l) & 1u;
+  float* __restrict__ tab = dtable + (size_t)lv.offset[l] * 2;
+  uint32_t cell[D];
+  float fr[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) pos_fract(x[d], scale, cell[d], fr[d]);
+#pragma unroll
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    uint32_t c[D];
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const bool hi = (corner >> d) & 1;
+      c[d] = cell[d] + (hi ? 1u : 0u);
+      w *= hi ? fr[d] : 1.0f - fr[d];
+    }
+    const uint32_t idx = grid_index<D>(c, size, res, hashed, pow2);
+    unsafeAtomicAdd(tab + (size_t)idx * 2, w * g.x);
+    unsafeAtomicAdd(tab + (size_t)idx * 2 + 1, w * g.y);
+  }
+}
+
+int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "encoding strides must be even (float2 stores)");
+  dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
+  Lattice L{};
+  if (lat) L = *lat;
+  const float2* t = reinterpret_cast<const float2*>(table);
+  if (lv.dims == 2) {
+    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    else hashgrid_fwd_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
+  } else {
+    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    else hashgrid_fwd_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
+  }
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_hashgrid_bwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
+                        const float* denc, int64_t ps, int64_t ls, float* dtable, hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "encoding strides must be even (float2 loads)");
+  dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
+  Lattice L{};
+  if (lat) L = *lat;
+  if (lv.dims == 2) {
+    if (lat) hashgrid_bwd_atomic_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, denc, ps, ls, dtable);
+    else hashgrid_bwd_atomic_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, denc, ps, ls, dtable);
+  } else {
+    if (lat) hashgrid_bwd_atomic_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, denc, ps, ls, dtable);
+    else hashgrid_bwd_atomic_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, denc, ps, ls, dtable);
+  }
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// parameter init (shared bit-exactly with oracle.uniform_init)
+__global__ __launch_bounds__(256) void init_uniform_kernel(float* __restrict__ out, int64_t n, uint32_t key,
+                                                           float lo, float span) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t h = pcg_hash((uint32_t)i + key);
+  const float u = (float)(h >> 8) * 5.9604644775390625e-08f;  // 2^-24
+  out[i] = __fadd_rn(lo, __fmul_rn(u, span));
+}
+
+int launch_init_uniform(float* out, int64_t n, uint32_t seed, uint32_t stream_id, float lo, float hi,
+                        hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  const uint32_t key = pcg_hash(seed ^ (stream_id * 0x9E3779B9u));
+  init_uniform_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(out, n, key, lo, hi - lo);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+}  // namespace immoco
+
+using namespace immoco;
+
+extern "C" int immoco_grid_geometry_query(const immoco_grid_cfg* cfg, immoco_grid_geometry* out) {
+  Levels lv;
+  int rc = build_levels(cfg, &lv);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(out != nullptr, "geometry out is NULL");
+  memset(out, 0, sizeof(*out));
+  for (int l = 0; l < lv.n_levels; ++l) {
+    out->offset[l] = lv.offset[l];
+    out->resolution[l] = lv.res[l];
+    out->size[l] = lv.size[l];
+    out->scale[l] = lv.scale[l];
+    out->hashed[l] = (lv.hashed >> l) & 1u;
+  }
+  out->offset[lv.n_levels] = lv.offset[lv.n_levels];
+  return IMMOCO_OK;
+}
+
+extern "C" int immoco_hashgrid_fwd(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
+                                   const float* table, float* enc, int64_t enc_point_stride,
+                                   int64_t enc_level_stride, void* stream) {
+  Levels lv;
+  int rc = build_levels(cfg, &lv);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(n >= 0 && (n == 0 || (coords && table && enc)), "hashgrid_fwd: NULL buffer");
+  return launch_hashgrid_fwd(lv, coords, nullptr, n, table, enc, enc_point_stride, enc_level_stride,
+                             as_stream(stream));
+}
+
+extern "C" int immoco_hashgrid_bwd(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
+                                   const float* denc, int64_t enc_point_stride, int64_t enc_level_stride,
+                                   float* dtable, void* stream) {
+  Levels lv;
+  int rc = build_levels(cfg, &lv);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(n >= 0 && (n == 0 || (coords && denc && dtable)), "hashgrid_bwd: NULL buffer");
+  return launch_hashgrid_bwd(lv, coords, nullptr, n, denc, enc_point_stride, enc_level_stride, dtable,
+                             as_stream(stream));
+}
+
+extern "C" int immoco_init_params(const immoco_grid_cfg* grid, const immoco_mlp_cfg* mlp, uint32_t seed,
+                                  float* params, void* stream) {
+  Levels lv;
+  int rc = build_levels(grid, &lv);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(mlp && params, "init_params: NULL argument");
+  const int64_t n_w1 = (int64_t)mlp->n_hidden * mlp->n_in;
+  const int64_t n_w2 = (int64_t)mlp->n_out_padded * mlp->n_hidden;
+  const int64_t n_tab = (int64_t)lv.offset[lv.n_levels] * 2;
+  const float b1 = (float)sqrt(6.0 / (double)(mlp->n_in + mlp->n_hidden));
+  const float b2 = (float)sqrt(6.0 / (double)(mlp->n_hidden + mlp->n_out_padded));
+  hipStream_t st = as_stream(stream);
+  if ((rc = launch_init_uniform(params, n_w1, seed, 1, -b1, b1, st))) return rc;
+  if ((rc = launch_init_uniform(params + n_w1, n_w2, seed, 2, -b2, b2, st))) return rc;
+  return launch_init_uniform(params + n_w1 + n_w2, n_tab, seed, 3, -1e-4f, 1e-4f, st);
+}

@@ -1,0 +1,71 @@
+// Internal launch API shared by the op-level C-ABI wrappers and the fused solver.
+#pragma once
+#include "common.hpp"
+
+namespace immoco {
+
+// Per-axis coordinate lattice: point p has coordinate axis[d][(p / stride[d]) % n[d]] in dim d.
+struct Lattice {
+  const float* axis[3];
+  int32_t n[3];
+  int32_t stride[3];
+};
+
+// hashgrid.hip
+int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st);
+int launch_hashgrid_bwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
+                        const float* denc, int64_t ps, int64_t ls, float* dtable, hipStream_t st);
+int launch_init_uniform(float* out, int64_t n, uint32_t seed, uint32_t stream_id, float lo, float hi,
+                        hipStream_t st);
+
+// mlp.hip
+int check_mlp_cfg(const immoco_mlp_cfg* cfg);
+int launch_mlp_fwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                   const float* w1, const float* w2, float* out, hipStream_t st);
+int launch_mlp_bwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                   const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
+                   hipStream_t st);
+
+// warp.hip
+int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st);
+int launch_warp_bwd(const float* image, const float* grids, const float* dout, int nM, int H, int W,
+                    float* dimage, float* dgrids, hipStream_t st);
+// solver-fused variants: motion-MLP output o [nM*H*W,2] -> t = tanh(o), grid = t + identity,
+// warped image * sign(r,c) -> fftbuf slots 1..nM; and its backward.
+int launch_motion_warp_fwd(const float* image, const float* o, const float* xs, const float* ys, int nM,
+                           int H, int W, float* t_out, float* fft_slots, hipStream_t st);
+int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, const float* ys,
+                           const float* adj_slots, int nM, int H, int W, float* dimage, float* d_o,
+                           hipStream_t st);
+
+// kspace.hip
+int fft2c(const float* in, float* out, int batch, int H, int W, int mode, hipStream_t st);
+int fft_exec_inplace(float* buf, int batch, int H, int W, bool inverse, hipStream_t st);  // raw, no shifts
+int launch_kspace_select(const float* kall, const int32_t* col_group, int nM, int H, int W, float* kout,
+                         hipStream_t st);
+int launch_dc_loss(const float* k, const float* kin, int H, int W, float* loss, float* dk, hipStream_t st);
+int launch_ge_loss(const float* image, int H, int W, float weight, const float* weight_dev, float* loss,
+                   float* dimage, hipStream_t st);
+int launch_normalize(const float* k, int64_t n, float target, float* out, float* scale_out, hipStream_t st);
+// solver-fused: image (H,W) c64 -> sign-modulated copy into fft slot 0
+int launch_image_to_slot(const float* image, int H, int W, float* slot0, hipStream_t st);
+// solver-fused select + DC loss + adjoint seed written back into the fft buffer
+// (loss goes to loss_hist[*iter_dev] when loss_hist != NULL)
+int launch_select_dc_seed(float* fftbuf, const int32_t* col_group, const float* kin, int nM, int H, int W,
+                          float* kout, float* loss_hist, const int32_t* iter_dev, hipStream_t st);
+// solver-fused: dimage = sign*adjoint slot 0 + lambda*dGE ; loss += lambda*GE, lambda = lambda_sched[*iter_dev]
+int launch_image_grad_init(const float* image, const float* adj_slot0, int H, int W, const float* lambda_sched,
+                           const int32_t* iter_dev, float* loss_hist, float* dimage, hipStream_t st);
+
+// optim.hip
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
+                float beta1, float beta2, float eps, hipStream_t st);
+// device-scheduled variant: scalars read from sched[2*it], it = *iter_dev; g zeroed after use
+int launch_adam_sched(float* p, float* g, float* m, float* v, int64_t n, const float* sched,
+                      const int32_t* iter_dev, float beta1, float beta2, float eps, hipStream_t st);
+
+// masks.hip
+int launch_extract_groups(const uint8_t* lines, int n, int32_t* col_group, int32_t* n_groups, hipStream_t st);
+
+}  // namespace immoco

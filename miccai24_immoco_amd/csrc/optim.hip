@@ -1,0 +1,90 @@
+// torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad) as the
+// reference uses it (src/models/immoco.py:149-154,166,175), restated from the
+// single-tensor torch implementation:
+//   m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// HBM-bound: 16-byte loads/stores, grid-stride, 28 B/param (+4 B when the fused
+// zero_grad write is enabled).
+#include "kernels.hpp"
+
+namespace immoco {
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt,
+                                         float b1, float b2, float eps) {
+  m = m + (g - m) * (1.0f - b1);
+  v = v * b2 + (1.0f - b2) * g * g;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);
+}
+
+template <bool SCHED>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float step_size, float bc2_sqrt,
+                                                   const float* __restrict__ sched,
+                                                   const int32_t* __restrict__ iter_dev, float b1, float b2,
+                                                   float eps) {
+  if (SCHED) {
+    const int it = *iter_dev;
+    step_size = sched[2 * it];
+    bc2_sqrt = sched[2 * it + 1];
+  }
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, step_size, bc2_sqrt, b1, b2, eps);
+    adam_one(pp.y, gg.y, mm.y, vv.y, step_size, bc2_sqrt, b1, b2, eps);
+    adam_one(pp.z, gg.z, mm.z, vv.z, step_size, bc2_sqrt, b1, b2, eps);
+    adam_one(pp.w, gg.w, mm.w, vv.w, step_size, bc2_sqrt, b1, b2, eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (SCHED) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // fused zero_grad
+  }
+  // tail
+  const int64_t t = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) {
+    adam_one(p[t], g[t], m[t], v[t], step_size, bc2_sqrt, b1, b2, eps);
+    if (SCHED) g[t] = 0.f;
+  }
+}
+
+static unsigned adam_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4 + 1, 256), 2048)); }
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
+                float beta1, float beta2, float eps, hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
+  adam_kernel<false><<<adam_grid(n), 256, 0, st>>>(p, const_cast<float*>(g), m, v, n, step_size, bc2_sqrt,
+                                                   nullptr, nullptr, beta1, beta2, eps);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_adam_sched(float* p, float* g, float* m, float* v, int64_t n, const float* sched,
+                      const int32_t* iter_dev, float beta1, float beta2, float eps, hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
+  adam_kernel<true><<<adam_grid(n), 256, 0, st>>>(p, g, m, v, n, 0.f, 1.f, sched, iter_dev, beta1, beta2, eps);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+}  // namespace immoco
+
+using namespace immoco;
+
+extern "C" int immoco_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, int32_t step, void* stream) {
+  IMMOCO_REQUIRE(n >= 0 && step >= 1 && (n == 0 || (p && g && m && v)), "adam_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  return launch_adam(p, g, m, v, n, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps,
+                     as_stream(stream));
+}

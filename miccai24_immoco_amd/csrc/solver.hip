@@ -1,0 +1,433 @@
+// Fused per-slice solver: the whole of imcoco_motion_correction's hot loop
+// (reference src/models/immoco.py:116-206) as a fixed sequence of HIP kernels +
+// two batched rocFFT executions per Adam iteration, captured once into a
+// hipGraph and replayed `iters` times.  Everything iteration-dependent (Adam
+// bias corrections, the GE weight lambda_j of immoco.py:180-181, the loss slot)
+// is read on the device from small schedule arrays indexed by a device-side
+// iteration counter, so the captured graph is iteration-invariant and the host
+// never synchronises inside the loop.
+#include <math.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace immoco {
+
+__global__ void tick_kernel(int32_t* it) { *it += 1; }
+
+struct Step {
+  const char* name;
+  std::function<int(hipStream_t)> run;
+};
+
+}  // namespace immoco
+
+using namespace immoco;
+
+struct immoco_solver {
+  immoco_solver_cfg cfg;
+  Levels lv_img, lv_mot;
+  int64_t P = 0, NP = 0;
+  int64_t n_w_img = 0, n_w_mot = 0;  // MLP weights (W1+W2)
+  int64_t n_params_img = 0, n_params_mot = 0;
+  // device workspace
+  float *enc_img = nullptr, *enc_mot = nullptr, *image = nullptr, *o_mot = nullptr, *t_mot = nullptr;
+  float *fftbuf = nullptr, *dimage = nullptr, *grad_img = nullptr, *grad_mot = nullptr, *kout = nullptr;
+  float *sched = nullptr, *lambda_dev = nullptr;
+  int32_t* iter_dev = nullptr;
+  int32_t sched_cap = 0;
+  int64_t bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // graph cache: valid while the captured pointers stay the same
+  hipGraphExec_t gexec = nullptr;
+  std::vector<const void*> gkey;
+  int graph_active = 0;
+  // phase timing of the last profile call
+  std::vector<std::string> phase_names;
+  std::vector<float> phase_ms;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(immoco_solver* s, T** p, int64_t count) {
+  IMMOCO_CHECK_HIP(hipMalloc((void**)p, (size_t)count * sizeof(T)));
+  s->bytes += count * (int64_t)sizeof(T);
+  return IMMOCO_OK;
+}
+
+struct Bind {
+  const float* kin;
+  const int32_t* col_group;
+  const float *xs, *ys, *ms;
+  float *p_img, *p_mot, *a_img, *a_mot;
+  float* loss_hist;
+};
+
+// The per-iteration kernel sequence (immoco.py:166-175).
+std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
+  const immoco_solver_cfg& c = s->cfg;
+  const int H = c.H, W = c.W, nM = c.nM;
+  const int64_t P = s->P, NP = s->NP;
+  Lattice li{}, lm{};
+  // image INR: identy_grid.view(-1,2) = (x = xs[col], y = ys[row])  (immoco.py:72-76,85)
+  li.axis[0] = b.xs; li.n[0] = W; li.stride[0] = 1;
+  li.axis[1] = b.ys; li.n[1] = H; li.stride[1] = W;
+  li.axis[2] = b.xs; li.n[2] = 1; li.stride[2] = 1;
+  // motion INR: make_grids((nM,H,W)) = (m, row, col)  (immoco.py:48-53,78-80,93)
+  lm.axis[0] = b.ms; lm.n[0] = nM; lm.stride[0] = H * W;
+  lm.axis[1] = b.ys; lm.n[1] = H; lm.stride[1] = W;
+  lm.axis[2] = b.xs; lm.n[2] = W; lm.stride[2] = 1;
+  float* w1i = b.p_img;
+  float* w2i = w1i + (int64_t)c.image_mlp.n_hidden * c.image_mlp.n_in;
+  float* tabi = b.p_img + s->n_w_img;
+  float* w1m = b.p_mot;
+  float* w2m = w1m + (int64_t)c.motion_mlp.n_hidden * c.motion_mlp.n_in;
+  float* tabm = b.p_mot + s->n_w_mot;
+  float* g_w1i = s->grad_img;
+  float* g_w2i = g_w1i + (int64_t)c.image_mlp.n_hidden * c.image_mlp.n_in;
+  float* g_tabi = s->grad_img + s->n_w_img;
+  float* g_w1m = s->grad_mot;
+  float* g_w2m = g_w1m + (int64_t)c.motion_mlp.n_hidden * c.motion_mlp.n_in;
+  float* g_tabm = s->grad_mot + s->n_w_mot;
+  float* slot1 = s->fftbuf + 2 * P;
+
+  std::vector<Step> st;
+  st.push_back({"image_encode_fwd", [=](hipStream_t q) {
+                  return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, 2, 2 * P, q);
+                }});
+  st.push_back({"image_mlp_fwd", [=](hipStream_t q) {
+                  return launch_mlp_fwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
+                }});
+  st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }});
+  if (nM > 0) {
+    st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
+                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
+                  }});
+    st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
+                    return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
+                  }});
+    st.push_back({"motion_warp_fwd", [=](hipStream_t q) {
+                    return launch_motion_warp_fwd(s->image, s->o_mot, b.xs, b.ys, nM, H, W, s->t_mot, slot1, q);
+                  }});
+  }
+  st.push_back({"fft_fwd", [=](hipStream_t q) { return fft_exec_inplace(s->fftbuf, nM + 1, H, W, false, q); }});
+  st.push_back({"select_dc_seed", [=](hipStream_t q) {
+                  return launch_select_dc_seed(s->fftbuf, b.col_group, b.kin, nM, H, W, s->kout, b.loss_hist,
+                                               s->iter_dev, q);
+                }});
+  if (!backward) return st;
+  st.push_back({"fft_adjoint", [=](hipStream_t q) { return fft_exec_inplace(s->fftbuf, nM + 1, H, W, true, q); }});
+  st.push_back({"image_grad_init_ge", [=](hipStream_t q) {
+                  return launch_image_grad_init(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
+                                                b.loss_hist, s->dimage, q);
+                }});
+  if (nM > 0) {
+    st.push_back({"motion_warp_bwd", [=](hipStream_t q) {
+                    return launch_motion_warp_bwd(s->image, s->t_mot, b.xs, b.ys, slot1, nM, H, W, s->dimage,
+                                                  s->o_mot, q);
+                  }});
+    st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
+                    return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
+                                          s->enc_mot, g_w1m, g_w2m, q);
+                  }});
+    st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
+                    return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
+                  }});
+  }
+  st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
+                  return launch_mlp_bwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
+                                        g_w1i, g_w2i, q);
+                }});
+  st.push_back({"image_encode_bwd", [=](hipStream_t q) {
+                  return launch_hashgrid_bwd(s->lv_img, nullptr, &li, P, s->enc_img, 2, 2 * P, g_tabi, q);
+                }});
+  // optimizer param-group order of the reference: motion first, then image (immoco.py:149-154)
+  if (nM > 0)
+    st.push_back({"adam_motion", [=](hipStream_t q) {
+                    return launch_adam_sched(b.p_mot, s->grad_mot, b.a_mot, b.a_mot + s->n_params_mot,
+                                             s->n_params_mot, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
+                  }});
+  st.push_back({"adam_image", [=](hipStream_t q) {
+                  return launch_adam_sched(b.p_img, s->grad_img, b.a_img, b.a_img + s->n_params_img,
+                                           s->n_params_img, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
+                }});
+  st.push_back({"tick", [=](hipStream_t q) {
+                  tick_kernel<<<1, 1, 0, q>>>(s->iter_dev);
+                  IMMOCO_LAUNCH_CHECK();
+                  return IMMOCO_OK;
+                }});
+  return st;
+}
+
+int run_steps(const std::vector<Step>& steps, hipStream_t q) {
+  for (const Step& st : steps) {
+    int rc = st.run(q);
+    if (rc) return rc;
+  }
+  return IMMOCO_OK;
+}
+
+int ensure_sched(immoco_solver* s, int32_t iters) {
+  if (iters <= s->sched_cap) return IMMOCO_OK;
+  if (s->sched) IMMOCO_CHECK_HIP(hipFree(s->sched));
+  if (s->lambda_dev) IMMOCO_CHECK_HIP(hipFree(s->lambda_dev));
+  s->sched = s->lambda_dev = nullptr;
+  IMMOCO_CHECK_HIP(hipMalloc((void**)&s->sched, (size_t)iters * 2 * sizeof(float)));
+  IMMOCO_CHECK_HIP(hipMalloc((void**)&s->lambda_dev, (size_t)iters * sizeof(float)));
+  s->sched_cap = iters;
+  // the schedule pointers are baked into a captured graph
+  if (s->gexec) {
+    hipGraphExecDestroy(s->gexec);
+    s->gexec = nullptr;
+  }
+  return IMMOCO_OK;
+}
+
+int enter(immoco_solver* s, hipStream_t caller) {
+  IMMOCO_CHECK_HIP(hipEventRecord(s->ev_in, caller));
+  IMMOCO_CHECK_HIP(hipStreamWaitEvent(s->stream, s->ev_in, 0));
+  return IMMOCO_OK;
+}
+int leave(immoco_solver* s, hipStream_t caller) {
+  IMMOCO_CHECK_HIP(hipEventRecord(s->ev_out, s->stream));
+  IMMOCO_CHECK_HIP(hipStreamWaitEvent(caller, s->ev_out, 0));
+  return IMMOCO_OK;
+}
+
+}  // namespace
+
+extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_t* out) {
+  IMMOCO_REQUIRE(cfg && out, "solver_create: NULL argument");
+  IMMOCO_REQUIRE(cfg->H >= 2 && cfg->W >= 2 && cfg->nM >= 0, "solver_create: bad shape H=%d W=%d nM=%d", cfg->H,
+                 cfg->W, cfg->nM);
+  IMMOCO_REQUIRE((cfg->H % 2) == 0 && (cfg->W % 2) == 0,
+                 "solver_create: H and W must be even (centred-FFT sign folding), got %dx%d", cfg->H, cfg->W);
+  IMMOCO_REQUIRE(cfg->image_grid.dims == 2 && cfg->motion_grid.dims == 3, "solver_create: grids must be 2-D/3-D");
+  IMMOCO_REQUIRE(cfg->image_grid.n_levels == 16 && cfg->motion_grid.n_levels == 16,
+                 "solver_create: 16 levels x 2 features expected");
+  int rc;
+  if ((rc = check_mlp_cfg(&cfg->image_mlp)) || (rc = check_mlp_cfg(&cfg->motion_mlp))) return rc;
+  immoco_solver* s = new immoco_solver();
+  s->cfg = *cfg;
+  if ((rc = build_levels(&cfg->image_grid, &s->lv_img)) || (rc = build_levels(&cfg->motion_grid, &s->lv_mot))) {
+    delete s;
+    return rc;
+  }
+  s->P = (int64_t)cfg->H * cfg->W;
+  s->NP = s->P * cfg->nM;
+  s->n_w_img = (int64_t)cfg->image_mlp.n_hidden * (cfg->image_mlp.n_in + cfg->image_mlp.n_out_padded);
+  s->n_w_mot = (int64_t)cfg->motion_mlp.n_hidden * (cfg->motion_mlp.n_in + cfg->motion_mlp.n_out_padded);
+  s->n_params_img = s->n_w_img + 2 * (int64_t)s->lv_img.offset[16];
+  s->n_params_mot = s->n_w_mot + 2 * (int64_t)s->lv_mot.offset[16];
+  const int64_t NPa = s->NP > 0 ? s->NP : 1;
+#define A(ptr, cnt)                       \
+  if ((rc = dev_alloc(s, &s->ptr, cnt))) { \
+    immoco_solver_destroy(s);             \
+    return rc;                            \
+  }
+  A(enc_img, 32 * s->P)
+  A(enc_mot, 32 * NPa)
+  A(image, 2 * s->P)
+  A(o_mot, 2 * NPa)
+  A(t_mot, 2 * NPa)
+  A(fftbuf, 2 * s->P * (cfg->nM + 1))
+  A(dimage, 2 * s->P)
+  A(kout, 2 * s->P)
+  A(grad_img, s->n_params_img)
+  A(grad_mot, s->n_params_mot)
+  A(iter_dev, 4)
+#undef A
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMemset(s->grad_img, 0, (size_t)s->n_params_img * 4);
+  if (e == hipSuccess) e = hipMemset(s->grad_mot, 0, (size_t)s->n_params_mot * 4);
+  if (e != hipSuccess) {
+    set_error("solver_create: %s", hipGetErrorString(e));
+    immoco_solver_destroy(s);
+    return IMMOCO_E_HIP;
+  }
+  // create the FFT plan now (rocFFT may compile kernels) so that solve() never does
+  if ((rc = fft_exec_inplace(s->fftbuf, cfg->nM + 1, cfg->H, cfg->W, false, s->stream))) {
+    immoco_solver_destroy(s);
+    return rc;
+  }
+  IMMOCO_CHECK_HIP(hipStreamSynchronize(s->stream));
+  *out = s;
+  return IMMOCO_OK;
+}
+
+extern "C" int immoco_solver_destroy(immoco_solver_t s) {
+  if (!s) return IMMOCO_OK;
+  if (s->gexec) hipGraphExecDestroy(s->gexec);
+  float* bufs[] = {s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
+                   s->kout,    s->grad_img, s->grad_mot, s->sched, s->lambda_dev};
+  for (float* b : bufs)
+    if (b) hipFree(b);
+  if (s->iter_dev) hipFree(s->iter_dev);
+  if (s->ev_in) hipEventDestroy(s->ev_in);
+  if (s->ev_out) hipEventDestroy(s->ev_out);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+  return IMMOCO_OK;
+}
+
+extern "C" int64_t immoco_solver_workspace_bytes(immoco_solver_t s) { return s ? s->bytes : 0; }
+
+extern "C" int64_t immoco_solver_n_params(immoco_solver_t s, int32_t which) {
+  if (!s) return 0;
+  return which == 0 ? s->n_params_img : s->n_params_mot;
+}
+
+extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
+                                   const float* xs, const float* ys, const float* ms, float* params_image,
+                                   float* params_motion, float* adam_image, float* adam_motion, int32_t iters,
+                                   float lr, const float* lambda_sched, int32_t step0, float* out_image,
+                                   float* out_kspace, float* loss_hist, void* stream) {
+  IMMOCO_REQUIRE(s, "solver_solve: NULL solver");
+  IMMOCO_REQUIRE(kspace_in && col_group && xs && ys && params_image && adam_image, "solver_solve: NULL buffer");
+  IMMOCO_REQUIRE(s->cfg.nM == 0 || (ms && params_motion && adam_motion), "solver_solve: NULL motion buffer");
+  IMMOCO_REQUIRE(iters >= 1 && lambda_sched && step0 >= 0, "solver_solve: bad iters/schedule");
+  hipStream_t caller = as_stream(stream);
+  int rc;
+  if ((rc = ensure_sched(s, iters))) return rc;
+  // host-side scalars in double like python/torch (immoco.py:180-181; torch Adam bias corrections)
+  std::vector<float> sched(2 * (size_t)iters), lam((size_t)iters);
+  for (int j = 0; j < iters; ++j) {
+    const double t = (double)(step0 + j + 1);
+    sched[2 * j] = (float)((double)lr / (1.0 - pow(0.9, t)));
+    sched[2 * j + 1] = (float)sqrt(1.0 - pow(0.999, t));
+    lam[j] = lambda_sched[j];
+  }
+  if ((rc = enter(s, caller))) return rc;
+  hipStream_t q = s->stream;
+  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, q));
+  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
+  IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
+  if (loss_hist) IMMOCO_CHECK_HIP(hipMemsetAsync(loss_hist, 0, (size_t)iters * 4, q));
+  IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
+
+  Bind b{kspace_in, col_group, xs, ys, ms, params_image, params_motion, adam_image, adam_motion, loss_hist};
+  std::vector<Step> steps = build_steps(s, b, true);
+  s->graph_active = 0;
+  if (s->cfg.use_graph) {
+    std::vector<const void*> key = {kspace_in, col_group, xs,          ys,          ms,       params_image,
+                                    params_motion, adam_image, adam_motion, loss_hist, s->sched};
+    if (!s->gexec || key != s->gkey) {
+      if (s->gexec) {
+        hipGraphExecDestroy(s->gexec);
+        s->gexec = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        rc = run_steps(steps, q);
+        hipError_t e2 = hipStreamEndCapture(q, &graph);
+        if (rc == IMMOCO_OK && e2 == hipSuccess && graph) {
+          if (hipGraphInstantiate(&s->gexec, graph, nullptr, nullptr, 0) != hipSuccess) s->gexec = nullptr;
+        }
+        if (graph) hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+      s->gkey = key;
+    }
+    s->graph_active = s->gexec != nullptr;
+  }
+  for (int j = 0; j < iters; ++j) {
+    if (s->graph_active) {
+      IMMOCO_CHECK_HIP(hipGraphLaunch(s->gexec, q));
+    } else if ((rc = run_steps(steps, q))) {
+      return rc;
+    }
+  }
+  // tensors of the LAST forward pass (immoco.py:203-206)
+  if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
+  if (out_kspace) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_kspace, s->kout, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
+  return leave(s, caller);
+}
+
+extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* xs, const float* ys,
+                                     const float* ms, const float* params_image, const float* params_motion,
+                                     float* out_image, float* out_kspace, void* stream) {
+  IMMOCO_REQUIRE(s && col_group && xs && ys && params_image, "solver_forward: NULL argument");
+  IMMOCO_REQUIRE(s->cfg.nM == 0 || (ms && params_motion), "solver_forward: NULL motion buffer");
+  hipStream_t caller = as_stream(stream);
+  int rc;
+  if ((rc = enter(s, caller))) return rc;
+  hipStream_t q = s->stream;
+  IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
+  // kin only feeds the (unused) residual here: point it at kout itself
+  Bind b{s->kout, col_group, xs, ys, ms, const_cast<float*>(params_image), const_cast<float*>(params_motion),
+         nullptr, nullptr, nullptr};
+  std::vector<Step> steps = build_steps(s, b, false);
+  if ((rc = run_steps(steps, q))) return rc;
+  if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
+  if (out_kspace) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_kspace, s->kout, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
+  return leave(s, caller);
+}
+
+// Times every step of one iteration with HIP events on the solver's own stream (eager launches,
+// `reps` repetitions, parameters and Adam state are advanced like in a real solve).
+extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
+                                     const float* xs, const float* ys, const float* ms, float* params_image,
+                                     float* params_motion, float* adam_image, float* adam_motion, int32_t reps,
+                                     float lr, float lambda_ge, void* stream) {
+  IMMOCO_REQUIRE(s && reps >= 1, "solver_profile: bad argument");
+  hipStream_t caller = as_stream(stream);
+  int rc;
+  if ((rc = ensure_sched(s, reps))) return rc;
+  std::vector<float> sched(2 * (size_t)reps), lam((size_t)reps, lambda_ge);
+  for (int j = 0; j < reps; ++j) {
+    const double t = (double)(j + 1);
+    sched[2 * j] = (float)((double)lr / (1.0 - pow(0.9, t)));
+    sched[2 * j + 1] = (float)sqrt(1.0 - pow(0.999, t));
+  }
+  if ((rc = enter(s, caller))) return rc;
+  hipStream_t q = s->stream;
+  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, q));
+  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
+  IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
+  IMMOCO_CHECK_HIP(hipStreamSynchronize(q));
+  Bind b{kspace_in, col_group, xs, ys, ms, params_image, params_motion, adam_image, adam_motion, nullptr};
+  std::vector<Step> steps = build_steps(s, b, true);
+  const size_t n = steps.size();
+  std::vector<hipEvent_t> ev((n + 1) * (size_t)reps);
+  for (auto& e : ev) IMMOCO_CHECK_HIP(hipEventCreate(&e));
+  for (int r = 0; r < reps; ++r) {
+    for (size_t i = 0; i < n; ++i) {
+      IMMOCO_CHECK_HIP(hipEventRecord(ev[r * (n + 1) + i], q));
+      if ((rc = steps[i].run(q))) return rc;
+    }
+    IMMOCO_CHECK_HIP(hipEventRecord(ev[r * (n + 1) + n], q));
+  }
+  IMMOCO_CHECK_HIP(hipStreamSynchronize(q));
+  s->phase_names.clear();
+  s->phase_ms.assign(n, 0.f);
+  for (size_t i = 0; i < n; ++i) s->phase_names.push_back(steps[i].name);
+  for (int r = 0; r < reps; ++r)
+    for (size_t i = 0; i < n; ++i) {
+      float ms_ = 0.f;
+      IMMOCO_CHECK_HIP(hipEventElapsedTime(&ms_, ev[r * (n + 1) + i], ev[r * (n + 1) + i + 1]));
+      s->phase_ms[i] += ms_ / (float)reps;
+    }
+  for (auto& e : ev) hipEventDestroy(e);
+  return leave(s, caller);
+}
+
+extern "C" int immoco_solver_phase_times(immoco_solver_t s, const char** names, float* ms, int32_t max_n) {
+  if (!s) return 0;
+  int n = (int)s->phase_names.size();
+  if (n > max_n) n = max_n;
+  for (int i = 0; i < n; ++i) {
+    if (names) names[i] = s->phase_names[i].c_str();
+    if (ms) ms[i] = s->phase_ms[i];
+  }
+  return n;
+}
+
+extern "C" int immoco_solver_graph_active(immoco_solver_t s) { return s ? s->graph_active : 0; }

@@ -1,0 +1,214 @@
+// Bilinear warp of ONE complex image at nM dense sampling grids, forward and
+// backward: F.grid_sample(mode="bilinear", padding_mode="zeros",
+// align_corners=False) as used by reference src/models/immoco.py:91,97-107
+// (ATen grid_sampler_2d semantics: x_pix = ((g+1)*W - 1)/2, taps nw/ne/sw/se,
+// out-of-bounds taps contribute 0; d/dgrid scaled by W/2, H/2).
+#include "kernels.hpp"
+
+namespace immoco {
+
+struct Taps {
+  int x0, y0;
+  float nw, ne, sw, se;  // weights
+  float tx0, tx1, ty0, ty1;  // (x1-x),(x-x0),(y1-y),(y-y0)
+};
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
+  Taps t;
+  const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+  const float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  // clamp the integer part so that wildly out-of-range grids cannot overflow int
+  t.x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+  t.y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+  t.tx0 = (fx + 1.f) - ix;
+  t.tx1 = ix - fx;
+  t.ty0 = (fy + 1.f) - iy;
+  t.ty1 = iy - fy;
+  t.nw = t.tx0 * t.ty0;
+  t.ne = t.tx1 * t.ty0;
+  t.sw = t.tx0 * t.ty1;
+  t.se = t.tx1 * t.ty1;
+  return t;
+}
+
+__device__ __forceinline__ bool inb(int y, int x, int H, int W) {
+  return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+}
+
+__device__ __forceinline__ float2 ld_or_zero(const float2* __restrict__ img, int y, int x, int H, int W) {
+  return inb(y, x, H, W) ? img[(size_t)y * W + x] : make_float2(0.f, 0.f);
+}
+
+__device__ __forceinline__ float2 sample(const float2* __restrict__ img, const Taps& t, int H, int W) {
+  const float2 a = ld_or_zero(img, t.y0, t.x0, H, W), b = ld_or_zero(img, t.y0, t.x0 + 1, H, W);
+  const float2 c = ld_or_zero(img, t.y0 + 1, t.x0, H, W), d = ld_or_zero(img, t.y0 + 1, t.x0 + 1, H, W);
+  // ATen accumulation order nw, ne, sw, se
+  float2 o;
+  o.x = a.x * t.nw;
+  o.x += b.x * t.ne;
+  o.x += c.x * t.sw;
+  o.x += d.x * t.se;
+  o.y = a.y * t.nw;
+  o.y += b.y * t.ne;
+  o.y += c.y * t.sw;
+  o.y += d.y * t.se;
+  return o;
+}
+
+// gradient wrt image (atomic scatter) and wrt the sampling position (returned, in grid units)
+__device__ __forceinline__ float2 sample_bwd(const float2* __restrict__ img, float* __restrict__ dimg,
+                                             const Taps& t, float2 go, int H, int W) {
+  const int x0 = t.x0, y0 = t.y0;
+  const float2 a = ld_or_zero(img, y0, x0, H, W), b = ld_or_zero(img, y0, x0 + 1, H, W);
+  const float2 c = ld_or_zero(img, y0 + 1, x0, H, W), d = ld_or_zero(img, y0 + 1, x0 + 1, H, W);
+  if (dimg) {
+    if (inb(y0, x0, H, W)) {
+      unsafeAtomicAdd(dimg + 2 * ((size_t)y0 * W + x0), t.nw * go.x);
+      unsafeAtomicAdd(dimg + 2 * ((size_t)y0 * W + x0) + 1, t.nw * go.y);
+    }
+    if (inb(y0, x0 + 1, H, W)) {
+      unsafeAtomicAdd(dimg + 2 * ((size_t)y0 * W + x0 + 1), t.ne * go.x);
+      unsafeAtomicAdd(dimg + 2 * ((size_t)y0 * W + x0 + 1) + 1, t.ne * go.y);
+    }
+    if (inb(y0 + 1, x0, H, W)) {
+      unsafeAtomicAdd(dimg + 2 * ((size_t)(y0 + 1) * W + x0), t.sw * go.x);
+      unsafeAtomicAdd(dimg + 2 * ((size_t)(y0 + 1) * W + x0) + 1, t.sw * go.y);
+    }
+    if (inb(y0 + 1, x0 + 1, H, W)) {
+      unsafeAtomicAdd(dimg + 2 * ((size_t)(y0 + 1) * W + x0 + 1), t.se * go.x);
+      unsafeAtomicAdd(dimg + 2 * ((size_t)(y0 + 1) * W + x0 + 1) + 1, t.se * go.y);
+    }
+  }
+  // ATen grid_sampler_2d_backward: sum over channels (re, im)
+  float gix = 0.f, giy = 0.f;
+  const float va = a.x * go.x + a.y * go.y, vb = b.x * go.x + b.y * go.y;
+  const float vc = c.x * go.x + c.y * go.y, vd = d.x * go.x + d.y * go.y;
+  gix -= va * t.ty0;
+  giy -= va * t.tx0;
+  gix += vb * t.ty0;
+  giy -= vb * t.tx1;
+  gix -= vc * t.ty1;
+  giy += vc * t.tx0;
+  gix += vd * t.ty1;
+  giy += vd * t.tx1;
+  return make_float2(gix * (0.5f * (float)W), giy * (0.5f * (float)H));
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float2* __restrict__ img,
+                                                       const float2* __restrict__ grids, int64_t n, int H,
+                                                       int W, float2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 g = grids[i];
+  out[i] = sample(img, make_taps(g.x, g.y, H, W), H, W);
+}
+
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float2* __restrict__ img,
+                                                       const float2* __restrict__ grids,
+                                                       const float2* __restrict__ dout, int64_t n, int H,
+                                                       int W, float* __restrict__ dimg,
+                                                       float2* __restrict__ dgrids) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 g = grids[i];
+  dgrids[i] = sample_bwd(img, dimg, make_taps(g.x, g.y, H, W), dout[i], H, W);
+}
+
+// solver: o (motion MLP output) -> t = tanh(o); grid = t + identity (immoco.py:93-95);
+// warped image, pre-multiplied by the FFT checkerboard sign, into fft slot 1+m.
+__global__ __launch_bounds__(256) void motion_warp_fwd_kernel(const float2* __restrict__ img,
+                                                              const float2* __restrict__ o,
+                                                              const float* __restrict__ xs,
+                                                              const float* __restrict__ ys, int64_t n, int H,
+                                                              int W, float2* __restrict__ t_out,
+                                                              float2* __restrict__ slots) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % W), r = (int)((i / W) % H);
+  const float2 ov = o[i];
+  const float2 t = make_float2(tanhf(ov.x), tanhf(ov.y));
+  t_out[i] = t;
+  float2 v = sample(img, make_taps(t.x + xs[c], t.y + ys[r], H, W), H, W);
+  const float s = ((r + c) & 1) ? -1.f : 1.f;
+  slots[i] = make_float2(v.x * s, v.y * s);
+}
+
+__global__ __launch_bounds__(256) void motion_warp_bwd_kernel(const float2* __restrict__ img,
+                                                              const float2* __restrict__ t_in,
+                                                              const float* __restrict__ xs,
+                                                              const float* __restrict__ ys,
+                                                              const float2* __restrict__ adj, int64_t n,
+                                                              int H, int W, float* __restrict__ dimg,
+                                                              float2* __restrict__ d_o) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % W), r = (int)((i / W) % H);
+  const float2 t = t_in[i];
+  const float s = ((r + c) & 1) ? -1.f : 1.f;
+  const float2 a = adj[i];
+  const float2 go = make_float2(a.x * s, a.y * s);
+  const float2 dg = sample_bwd(img, dimg, make_taps(t.x + xs[c], t.y + ys[r], H, W), go, H, W);
+  d_o[i] = make_float2(dg.x * (1.f - t.x * t.x), dg.y * (1.f - t.y * t.y));
+}
+
+int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st) {
+  const int64_t n = (int64_t)nM * H * W;
+  if (n == 0) return IMMOCO_OK;
+  warp_fwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float2*)image, (const float2*)grids, n, H, W,
+                                                          (float2*)out);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_warp_bwd(const float* image, const float* grids, const float* dout, int nM, int H, int W,
+                    float* dimage, float* dgrids, hipStream_t st) {
+  const int64_t n = (int64_t)nM * H * W;
+  if (n == 0) return IMMOCO_OK;
+  warp_bwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float2*)image, (const float2*)grids,
+                                                          (const float2*)dout, n, H, W, dimage,
+                                                          (float2*)dgrids);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_motion_warp_fwd(const float* image, const float* o, const float* xs, const float* ys, int nM,
+                           int H, int W, float* t_out, float* fft_slots, hipStream_t st) {
+  const int64_t n = (int64_t)nM * H * W;
+  if (n == 0) return IMMOCO_OK;
+  motion_warp_fwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float2*)image, (const float2*)o, xs,
+                                                                 ys, n, H, W, (float2*)t_out,
+                                                                 (float2*)fft_slots);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, const float* ys,
+                           const float* adj_slots, int nM, int H, int W, float* dimage, float* d_o,
+                           hipStream_t st) {
+  const int64_t n = (int64_t)nM * H * W;
+  if (n == 0) return IMMOCO_OK;
+  motion_warp_bwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float2*)image, (const float2*)t, xs,
+                                                                 ys, (const float2*)adj_slots, n, H, W,
+                                                                 dimage, (float2*)d_o);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+}  // namespace immoco
+
+using namespace immoco;
+
+extern "C" int immoco_warp_fwd(const float* image, const float* grids, int32_t nM, int32_t H, int32_t W,
+                               float* out, void* stream) {
+  IMMOCO_REQUIRE(nM >= 0 && H > 0 && W > 0, "warp_fwd: bad shape nM=%d H=%d W=%d", nM, H, W);
+  IMMOCO_REQUIRE(nM == 0 || (image && grids && out), "warp_fwd: NULL buffer");
+  return launch_warp_fwd(image, grids, nM, H, W, out, as_stream(stream));
+}
+
+extern "C" int immoco_warp_bwd(const float* image, const float* grids, const float* dout, int32_t nM,
+                               int32_t H, int32_t W, float* dimage, float* dgrids, void* stream) {
+  IMMOCO_REQUIRE(nM >= 0 && H > 0 && W > 0, "warp_bwd: bad shape nM=%d H=%d W=%d", nM, H, W);
+  IMMOCO_REQUIRE(nM == 0 || (image && grids && dout && dgrids), "warp_bwd: NULL buffer");
+  return launch_warp_bwd(image, grids, dout, nM, H, W, dimage, dgrids, as_stream(stream));
+}

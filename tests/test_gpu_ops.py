@@ -1,0 +1,443 @@
+"""GPU parity tests: every operator of the hot path, called through the C-ABI
+(ctypes -> libimmoco_hip.so), against the CPU oracle and the golden vectors.
+Run on the MI355X box with `pytest -m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import expand_masks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (no CPU fallback exists)")
+    import miccai24_immoco_amd as pkg
+    from miccai24_immoco_amd import _lib as L
+    from oracle import immoco_oracle as orc
+    L.lib()  # fail loudly if the HIP library is missing
+    return pkg, L, orc
+
+
+def dev(x):
+    return x.cuda()
+
+
+# ------------------------------------------------------------------ hash grid
+@pytest.mark.parametrize("dims", [2, 3])
+def test_hashgrid_fwd_bit_exact_and_bwd(env, dims):
+    pkg, L, orc = env
+    g = torch.Generator().manual_seed(dims)
+    n = 3001
+    coords = torch.rand(n, dims, generator=g) * 2 - 1
+    coords[0] = -1.0
+    coords[1] = 1.0
+    coords[2] = 0.0
+    geo = orc.geometry_from_config(dims, orc.encoding_config)
+    table = (torch.rand(geo.n_entries, 2, generator=g) - 0.5)
+    plan = orc.HashGridPlan(coords, geo)
+    ref = plan.encode(table)
+    cfg = L.grid_cfg(dims, pkg.encoding_config)
+    enc = torch.empty(n, 32, device="cuda")
+    cd, td = dev(coords), dev(table)
+    L.check(L.lib().immoco_hashgrid_fwd(C.byref(cfg), L.ptr(cd), n, L.ptr(td), L.ptr(enc), 32, 2, L.stream_ptr()))
+    got = enc.cpu()
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max()}"     # bit-exact (indices AND arithmetic)
+    # level-major layout used by the solver
+    enc2 = torch.empty(16, n, 2, device="cuda")
+    L.check(L.lib().immoco_hashgrid_fwd(C.byref(cfg), L.ptr(cd), n, L.ptr(td), L.ptr(enc2), 2, 2 * n, L.stream_ptr()))
+    assert torch.equal(enc2.cpu().permute(1, 0, 2).reshape(n, 32), ref)
+    # backward: scatter-add of weighted gradients
+    denc = torch.randn(n, 32, generator=g)
+    t = table.clone().requires_grad_(True)
+    (plan.encode(t) * denc).sum().backward()
+    dt = torch.zeros(geo.n_entries, 2, device="cuda")
+    dd = dev(denc)
+    L.check(L.lib().immoco_hashgrid_bwd(C.byref(cfg), L.ptr(cd), n, L.ptr(dd), 32, 2, L.ptr(dt), L.stream_ptr()))
+    err = (dt.cpu() - t.grad).abs().max() / t.grad.abs().max()
+    assert err < 1e-5, err
+
+
+def test_grid_geometry_matches_oracle(env):
+    pkg, L, orc = env
+    for dims in (2, 3):
+        geo = orc.geometry_from_config(dims, orc.encoding_config)
+        g = L.geometry(L.grid_cfg(dims, pkg.encoding_config))
+        assert list(g.offset) == geo.offsets
+        assert list(g.resolution) == geo.resolutions and list(g.size) == geo.sizes
+        assert [bool(h) for h in g.hashed] == geo.hashed
+        assert [float(s) for s in g.scale] == geo.scales
+
+
+@pytest.mark.parametrize("which", ["image", "motion"])
+def test_init_params_bit_exact(env, which):
+    pkg, L, orc = env
+    dims, net = (2, pkg.network_config) if which == "image" else (3, pkg.mot_network_config)
+    inr = pkg.NetworkWithInputEncoding(dims, 2, pkg.encoding_config, net, seed=1337)
+    ref = orc.init_inr_params(orc.geometry_from_config(dims, orc.encoding_config),
+                              orc.mlp_spec_from_config(32, 2, net), 1337)
+    assert inr.params.shape[0] == ref.shape[0]
+    assert np.array_equal(inr.params.detach().cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------ MLP
+@pytest.mark.parametrize("which", ["image", "motion"])
+@pytest.mark.parametrize("n", [64, 1000])
+def test_mlp_fwd_bwd(env, which, n):
+    pkg, L, orc = env
+    net = pkg.network_config if which == "image" else pkg.mot_network_config
+    cfg = L.mlp_cfg(32, 2, net)
+    hid, pad = cfg.n_hidden, cfg.n_out_padded
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 32, generator=g) * 0.5
+    w1 = (torch.randn(hid, 32, generator=g) * 0.2).requires_grad_(True)
+    w2 = (torch.randn(pad, hid, generator=g) * 0.2).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    pre = xr.double() @ w1.double().t()
+    h = torch.relu(pre) if which == "image" else torch.tanh(pre)
+    out = (h @ w2.double().t())[:, :2]
+    dout = torch.randn(n, 2, generator=g)
+    (out * dout.double()).sum().backward()
+    xd, w1d, w2d, dd = dev(x), dev(w1.detach()), dev(w2.detach()), dev(dout)
+    o = torch.empty(n, 2, device="cuda")
+    st = L.stream_ptr()
+    L.check(L.lib().immoco_mlp_fwd(C.byref(cfg), L.ptr(xd), 32, 2, n, L.ptr(w1d), L.ptr(w2d), L.ptr(o), st))
+    np.testing.assert_allclose(o.cpu().numpy(), out.detach().float().numpy(), rtol=2e-4, atol=2e-5)
+    dx = torch.empty(n, 32, device="cuda")
+    dw1 = torch.zeros(hid, 32, device="cuda")
+    dw2 = torch.zeros(pad, hid, device="cuda")
+    L.check(L.lib().immoco_mlp_bwd(C.byref(cfg), L.ptr(xd), 32, 2, n, L.ptr(w1d), L.ptr(w2d), L.ptr(dd), L.ptr(dx),
+                                   L.ptr(dw1), L.ptr(dw2), st))
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
+    s1, s2 = w1.grad.abs().max().item(), w2.grad.abs().max().item()
+    np.testing.assert_allclose(dw1.cpu().numpy(), w1.grad.numpy(), rtol=1e-3, atol=1e-4 * s1)
+    np.testing.assert_allclose(dw2.cpu().numpy()[:2], w2.grad.numpy()[:2], rtol=1e-3, atol=1e-4 * s2)
+    assert float(dw2[2:].abs().max()) == 0.0          # padded rows untouched
+    # in-place d-input (din aliases in), level-major strides, as the solver calls it
+    xl = xd.view(n, 16, 2).permute(1, 0, 2).contiguous()
+    dw1.zero_(), dw2.zero_()
+    L.check(L.lib().immoco_mlp_bwd(C.byref(cfg), L.ptr(xl), 2, 2 * n, n, L.ptr(w1d), L.ptr(w2d), L.ptr(dd), L.ptr(xl),
+                                   L.ptr(dw1), L.ptr(dw2), st))
+    np.testing.assert_allclose(xl.permute(1, 0, 2).reshape(n, 32).cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dw1.cpu().numpy(), w1.grad.numpy(), rtol=1e-3, atol=1e-4 * s1)
+
+
+@pytest.mark.parametrize("which", ["image", "motion"])
+def test_inr_module_vs_oracle(env, which):
+    """NetworkWithInputEncoding (tcnn-compatible module) forward/backward vs the oracle INR."""
+    pkg, L, orc = env
+    dims, net = (2, pkg.network_config) if which == "image" else (3, pkg.mot_network_config)
+    inr = pkg.NetworkWithInputEncoding(dims, 2, pkg.encoding_config, net, seed=7)
+    ref = orc.OracleINR(dims, 2, orc.encoding_config, net, seed=7)
+    with torch.no_grad():   # larger features so that the test is not dominated by 1e-4-sized values
+        ref.params[ref.mlp.n_params:] *= 1000
+        inr.params.copy_(ref.params.cuda())
+    x = orc.make_grids((3, 9, 11) if dims == 3 else (17, 13))
+    tgt = torch.randn(x.shape[0], 2, generator=torch.Generator().manual_seed(1))
+    out_ref = ref(x)
+    ((out_ref - tgt) ** 2).sum().backward()
+    out = inr(x.cuda())
+    ((out - tgt.cuda()) ** 2).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    gr, gg = ref.params.grad, inr.params.grad.cpu()
+    nw = ref.mlp.n_params
+    for a, b in ((gr[:nw], gg[:nw]), (gr[nw:], gg[nw:])):
+        assert (a - b).abs().max() <= 2e-4 * a.abs().max(), ((a - b).abs().max(), a.abs().max())
+
+
+# ----------------------------------------------------------------------- warp
+def test_warp_fwd_bwd_vs_grid_sample(env):
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.immoco import _Warp
+    g = torch.Generator().manual_seed(3)
+    H, W, nM = 20, 24, 3
+    img = torch.complex(torch.randn(H, W, generator=g), torch.randn(H, W, generator=g)).requires_grad_(True)
+    grid = (orc.identity_grid(H, W).expand(nM, H, W, 2) + 0.3 * torch.randn(nM, H, W, 2, generator=g))
+    grid[0, 0, 0] = torch.tensor([-1.5, 0.0])      # fully out of bounds
+    grid[0, 0, 1] = torch.tensor([1.0, 1.0])       # touches the border
+    grid = grid.clone().requires_grad_(True)
+    images = img.unsqueeze(0).repeat(nM, 1, 1)
+    ref = torch.view_as_complex(F.grid_sample(torch.view_as_real(images).permute(0, 3, 1, 2), grid, mode="bilinear",
+                                              align_corners=False, padding_mode="zeros").permute(0, 2, 3, 1).contiguous())
+    go = torch.complex(torch.randn(nM, H, W, generator=g), torch.randn(nM, H, W, generator=g))
+    (torch.view_as_real(ref) * torch.view_as_real(go)).sum().backward()
+    imd = img.detach().cuda().requires_grad_(True)
+    grd = grid.detach().cuda().requires_grad_(True)
+    out = _Warp.apply(imd, grd)
+    (torch.view_as_real(out) * torch.view_as_real(go.cuda())).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(imd.grad.cpu().numpy(), img.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(grd.grad.cpu().numpy(), grid.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------ FFT
+@pytest.mark.parametrize("tag", ["even", "mod2", "odd"])
+def test_fft_ifft_golden(env, golden, tag):
+    pkg, L, orc = env
+    g = golden("ops")
+    x = torch.from_numpy(g[f"fft_{tag}_in"]).cuda()
+    s = np.abs(g[f"fft_{tag}_out"]).max()
+    np.testing.assert_allclose(pkg.FFT(x).cpu().numpy(), g[f"fft_{tag}_out"], rtol=1e-4, atol=1e-5 * s)
+    np.testing.assert_allclose(pkg.IFFT(x).cpu().numpy(), g[f"ifft_{tag}_out"], rtol=1e-4, atol=1e-6)
+    # adjoint: <FFT x, y> == <x, FFT^H y>
+    y = torch.randn_like(x)
+    from miccai24_immoco_amd.utils.data_utils import _fft2c
+    lhs = torch.vdot(pkg.FFT(x).flatten(), y.flatten())
+    rhs = torch.vdot(x.flatten(), _fft2c(y, 2).flatten())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+    # IFFT(FFT(x)) == x
+    np.testing.assert_allclose(pkg.IFFT(pkg.FFT(x)).cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_fft_320_vs_torch(env):
+    pkg, L, orc = env
+    x = torch.randn(11, 320, 320, dtype=torch.complex64, generator=torch.Generator().manual_seed(0))
+    ref = orc.FFT(x)
+    got = pkg.FFT(x.cuda()).cpu()
+    assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+# --------------------------------------------------------------------- losses
+def test_gradient_entropy_golden(env, golden):
+    pkg, L, orc = env
+    g = golden("ops")
+    x = torch.from_numpy(g["ge_in"]).cuda().requires_grad_(True)
+    loss = pkg.GradientEntropyLoss()(x)
+    loss.backward()
+    assert abs(loss.item() - float(g["ge_loss"])) <= 1e-5 * abs(float(g["ge_loss"]))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["ge_grad"], rtol=1e-4, atol=1e-4)
+    assert np.isfinite(x.grad.cpu().numpy().view(np.float32)).all()
+
+
+def test_dc_loss_and_select(env):
+    pkg, L, orc = env
+    g = torch.Generator().manual_seed(5)
+    H, W, nM = 16, 20, 3
+    kall = torch.randn(nM + 1, H, W, dtype=torch.complex64, generator=g)
+    kin = torch.randn(H, W, dtype=torch.complex64, generator=g)
+    cg = torch.randint(0, nM + 1, (W,), generator=g, dtype=torch.int32)
+    ref = torch.stack([kall[cg[c], :, c] for c in range(W)], dim=1)
+    out = torch.empty(H, W, dtype=torch.complex64, device="cuda")
+    st = L.stream_ptr()
+    kd, cd = kall.cuda(), cg.cuda()
+    L.check(L.lib().immoco_kspace_select(L.ptr(kd), L.ptr(cd), nM, H, W, L.ptr(out), st))
+    assert torch.equal(out.cpu(), ref)                                  # pure indexing: bit-exact
+    # mask formulation of the reference (immoco.py:109-111) gives the same thing
+    masks = torch.stack([(cg == m + 1).long()[None, :].expand(H, W) for m in range(nM)])
+    ref2 = kall[0] * (1 - masks.sum(0)).float() + (kall[1:] * masks.float()).sum(0)
+    assert torch.equal(ref2, ref)
+    loss = torch.zeros(1, device="cuda")
+    dk = torch.empty(H, W, dtype=torch.complex64, device="cuda")
+    kid = kin.cuda()
+    L.check(L.lib().immoco_dc_loss(L.ptr(out), L.ptr(kid), H, W, L.ptr(loss), L.ptr(dk), st))
+    kr = ref.clone().requires_grad_(True)
+    lr = F.mse_loss(torch.view_as_real(kr), torch.view_as_real(kin))
+    lr.backward()
+    assert abs(loss.item() - lr.item()) <= 1e-5 * lr.item()
+    np.testing.assert_allclose(dk.cpu().numpy(), kr.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_normalize_kspace(env):
+    pkg, L, orc = env
+    k = torch.randn(32, 32, dtype=torch.complex64, generator=torch.Generator().manual_seed(2)) * 37
+    kd = k.cuda()
+    out = torch.empty_like(kd)
+    sc = torch.empty(1, device="cuda")
+    L.check(L.lib().immoco_normalize_kspace(L.ptr(kd), 32 * 32, 16000.0, L.ptr(out), L.ptr(sc), L.stream_ptr()))
+    scale = k.abs().max()
+    assert abs(sc.item() - scale.item()) <= 1e-6 * scale.item()
+    np.testing.assert_allclose(out.cpu().numpy(), k.div(scale).mul(16000).numpy(), rtol=1e-6)
+    assert abs(out.abs().max().item() - 16000) < 0.01
+
+
+# ----------------------------------------------------------------------- Adam
+def test_adam_vs_torch(env):
+    pkg, L, orc = env
+    g = torch.Generator().manual_seed(9)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-2)
+    p, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step - 3))
+        grad[:100] = 0.0
+        pr.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        L.check(L.lib().immoco_adam_step(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), n, 1e-2, 0.9, 0.999, 1e-8, step,
+                                         L.stream_ptr()))
+        np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(p[:100].cpu(), p0[:100])   # zero gradient => exactly no update
+
+
+# ---------------------------------------------------------------------- masks
+@pytest.mark.parametrize("tag", ["typical", "last_true", "first_true", "single", "all_true", "alternating",
+                                 "random320"])
+def test_extract_movement_groups_bit_exact(env, golden, tag):
+    pkg, L, orc = env
+    g = golden("masks")
+    v = torch.from_numpy(g[f"{tag}_vec"]).bool().cuda()
+    groups = pkg.extract_movement_groups(v, make_list=False)
+    assert groups.dtype == torch.int64 and groups.shape == (len(v), len(v))
+    assert np.array_equal(groups[0].cpu().numpy().astype(np.int32), g[f"{tag}_groups"])
+    assert bool((groups == groups[:1]).all())
+    ml = pkg.extract_movement_groups(v, make_list=True)
+    assert tuple(ml.shape) == tuple(g[f"{tag}_list_shape"]) and ml.dtype == torch.int64
+    assert np.array_equal(ml[:, 0, :].cpu().numpy().astype(np.uint8), g[f"{tag}_list_row0"])
+    assert bool((ml == ml[:, :1, :]).all())
+    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    assert np.array_equal(masks_to_col_group(ml).cpu().numpy(), g[f"{tag}_groups"])
+
+
+def test_extract_movement_groups_empty(env):
+    pkg, L, orc = env
+    ml = pkg.extract_movement_groups(torch.zeros(8, dtype=torch.bool, device="cuda"), make_list=True)
+    assert tuple(ml.shape) == (0, 8, 8)
+
+
+def test_cpu_tensor_is_refused(env):
+    pkg, L, orc = env
+    with pytest.raises(L.ImmocoError):
+        pkg.FFT(torch.zeros(4, 4, dtype=torch.complex64))
+    with pytest.raises(L.ImmocoError):
+        pkg.extract_movement_groups(torch.zeros(8, dtype=torch.bool))
+
+
+# ------------------------------------------------------- forward operator / solver
+def _golden_case(golden, tag):
+    g = golden("solver")
+    H = g[f"{tag}_gt"].shape[0]
+    return g, H, expand_masks(g[f"{tag}_masks_row0"], H)
+
+
+@pytest.mark.parametrize("tag", ["c32", "c48"])
+def test_immoco_forward_golden(env, golden, tag):
+    """IMMoCo.forward (module API) and the fused solver's forward vs the reference's forward."""
+    pkg, L, orc = env
+    g, H, masks = _golden_case(golden, tag)
+    model = pkg.IMMoCo(masks.cuda())
+    assert np.array_equal(model.identy_grid.cpu().numpy(), g[f"{tag}_identy_grid"])
+    assert np.array_equal(model.input_grid.cpu().numpy(), g[f"{tag}_input_grid"])
+    with torch.no_grad():
+        k0, im0 = model()
+    np.testing.assert_allclose(im0.cpu().numpy(), g[f"{tag}_fwd0_image"], rtol=1e-4, atol=1e-7)
+    sk = np.abs(g[f"{tag}_fwd0_kspace"]).max()
+    np.testing.assert_allclose(k0.cpu().numpy(), g[f"{tag}_fwd0_kspace"], rtol=1e-3, atol=2e-5 * sk)
+    from miccai24_immoco_amd.models.immoco import get_solver
+    s = get_solver("cuda", H, H, masks.shape[0])
+    k1, im1 = s.forward(model.col_group, model.image_inr.params.detach(), model.motion_inr.params.detach())
+    np.testing.assert_allclose(im1.cpu().numpy(), im0.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(k1.cpu().numpy(), k0.cpu().numpy(), rtol=1e-4, atol=2e-5 * sk)
+
+
+def test_immoco_module_gradients_vs_oracle(env, golden):
+    """loss.backward() through the module API == oracle autograd (immoco.py:170-174)."""
+    pkg, L, orc = env
+    g, H, masks = _golden_case(golden, "c32")
+    ksp = torch.from_numpy(g["c32_ksp"])
+    kin = ksp.div(ksp.abs().max()).mul(16000)
+    ref = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config),
+                           motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config))
+    kf, ip = ref()
+    lref = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(kin)) + orc.gradient_entropy_loss(ip) * 1e-2
+    lref.backward()
+    model = pkg.IMMoCo(masks.cuda())
+    k, im = model()
+    loss = F.mse_loss(torch.view_as_real(k), torch.view_as_real(kin.cuda())) + pkg.GradientEntropyLoss()(im) * 1e-2
+    loss.backward()
+    assert abs(loss.item() - lref.item()) <= 1e-4 * abs(lref.item())
+    for name in ("image_inr", "motion_inr"):
+        a = getattr(ref, name).params.grad
+        b = getattr(model, name).params.grad.cpu()
+        nw = getattr(ref, name).mlp.n_params
+        for lo, hi in ((0, nw), (nw, a.numel())):
+            err = (a[lo:hi] - b[lo:hi]).abs().max() / a[lo:hi].abs().max()
+            assert err < 2e-3, (name, lo, err)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_solver_first_steps_vs_oracle(env, golden, use_graph):
+    """Fused solver vs oracle loop on identical inputs and bit-identical initial parameters:
+    the first iterations must agree tightly (before Adam's chaos sets in)."""
+    pkg, L, orc = env
+    g, H, masks = _golden_case(golden, "c32")
+    ksp = torch.from_numpy(g["c32_ksp"])
+    hist = []
+    ref = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config),
+                           motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config))
+    img_ref, k_ref = orc.oracle_motion_correction(ksp, masks, iters=12, model=ref, loss_hist=hist)
+    img, kfm, loss = pkg.imcoco_motion_correction(ksp.cuda(), masks.cuda(), iters=12, return_loss=True,
+                                                  use_graph=use_graph)
+    from miccai24_immoco_amd.models.immoco import get_solver
+    assert get_solver("cuda", H, H, masks.shape[0], use_graph).graph_active == use_graph
+    lh = loss.cpu().numpy()
+    print("oracle loss", hist)
+    print("hip loss   ", lh.tolist())
+    np.testing.assert_allclose(lh[:4], np.array(hist[:4]), rtol=2e-3)
+    np.testing.assert_allclose(lh, np.array(hist), rtol=0.1)
+    e = np.linalg.norm(img.cpu().numpy() - img_ref.detach().numpy()) / np.linalg.norm(img_ref.detach().numpy())
+    assert e < 0.1, e
+
+
+@pytest.mark.parametrize("tag", ["c32", "c48"])
+def test_solver_psnr_parity_golden(env, golden, tag):
+    """Full solve vs the REFERENCE loop's golden result: PSNR delta <= 0.1 dB (north-star tolerance)."""
+    pkg, L, orc = env
+    g, H, masks = _golden_case(golden, tag)
+    iters = int(g[f"{tag}_iters"])
+    img, kfm = pkg.imcoco_motion_correction(torch.from_numpy(g[f"{tag}_ksp"]).cuda(), masks.cuda(), iters=iters,
+                                            learning_rate=1e-2, lambda_ge=1e-2)
+    gt = torch.from_numpy(g[f"{tag}_gt"]).abs()
+    ref = g[f"{tag}_image_prior"]
+    p_hip = orc.crop_psnr(img.abs().cpu(), gt)
+    p_ref = orc.crop_psnr(torch.from_numpy(np.abs(ref)), gt)
+    print(tag, "psnr hip", p_hip, "ref", p_ref)
+    assert abs(p_hip - p_ref) <= 0.1
+    e = np.linalg.norm(img.cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert e < 0.15, e
+    ek = np.linalg.norm(kfm.cpu().numpy() - g[f"{tag}_kfm"]) / np.linalg.norm(g[f"{tag}_kfm"])
+    assert ek < 0.15, ek
+
+
+def test_solver_returns_last_forward_not_final_params(env, golden):
+    """immoco.py:203-206: returned tensors come from the last forward, i.e. BEFORE the final Adam step."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.immoco import get_solver, lambda_schedule
+    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    g, H, masks = _golden_case(golden, "c32")
+    md = masks.cuda()
+    s = get_solver("cuda", H, H, masks.shape[0])
+    ksp = torch.from_numpy(g["c32_ksp"]).cuda()
+    kin = ksp / ksp.abs().max() * 16000
+    cg = masks_to_col_group(md)
+
+    def run(iters):
+        pi, pm = s.init_params()
+        ai, am = torch.zeros(2 * pi.numel(), device="cuda"), torch.zeros(2 * pm.numel(), device="cuda")
+        lam = lambda_schedule(20, 1e-2)[:iters]
+        img, k, _ = s.solve(kin, cg, pi, pm, ai, am, iters, 1e-2, lam)
+        return img, pi, pm, ai, am
+
+    img10, pi10, pm10, ai, am = run(10)
+    _, im_after = s.forward(cg, pi10, pm10)          # forward with the parameters AFTER step 10
+    assert (im_after - img10).abs().max() > 1e-3 * img10.abs().max()
+    # continuing for one more iteration (step0=10): its forward sees exactly those parameters
+    lam = lambda_schedule(20, 1e-2)
+    img11, _, _ = s.solve(kin, cg, pi10, pm10, ai, am, 1, 1e-2, lam[10:11], step0=10)
+    assert (im_after - img11).abs().max() <= 1e-5 * img11.abs().max()
+
+
+def test_lambda_schedule_quirk_and_errors(env):
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.immoco import lambda_schedule
+    assert lambda_schedule(50, 1e-2) == orc.lambda_schedule(50, 1e-2)
+    assert lambda_schedule(3000, 1e-2)[-1] == 0.0
+    with pytest.raises(ZeroDivisionError):
+        pkg.imcoco_motion_correction(torch.zeros(16, 16, dtype=torch.complex64).cuda(),
+                                     torch.zeros(1, 16, 16, dtype=torch.long).cuda(), iters=9)

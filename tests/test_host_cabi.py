@@ -1,0 +1,120 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol that
+include/immoco_hip.h declares; host-only entry points (geometry, argument
+validation) agree with the oracle; host logic of the Python mirror."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from miccai24_immoco_amd import _lib
+    if not _lib.lib_available():
+        import __graft_entry__ as ge
+        ge.build()
+    _lib.lib()
+    return _lib
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "immoco_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(immoco_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound(L):
+    names = declared_functions()
+    assert len(names) >= 25
+    h = L.lib()
+    for n in names:
+        assert hasattr(h, n), f"{n} declared in include/immoco_hip.h but not exported"
+        assert n in L.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert set(L.PROTOTYPES) == set(names)
+    assert h.immoco_version() >= 100
+
+
+def test_geometry_query_matches_oracle(L):
+    from oracle import immoco_oracle as orc
+    for dims in (2, 3):
+        for enc in (orc.encoding_config, dict(orc.encoding_config, per_level_scale=1.5, base_resolution=12,
+                                              log2_hashmap_size=15, n_levels=12)):
+            geo = orc.geometry_from_config(dims, enc)
+            g = L.geometry(L.grid_cfg(dims, enc))
+            nl = geo.n_levels
+            assert list(g.offset)[: nl + 1] == geo.offsets
+            assert list(g.resolution)[:nl] == geo.resolutions and list(g.size)[:nl] == geo.sizes
+            assert [bool(x) for x in list(g.hashed)[:nl]] == geo.hashed
+            if enc is orc.encoding_config:      # the reference's config: exact (powers of two)
+                assert [float(x) for x in list(g.scale)[:nl]] == geo.scales
+            else:                               # exp2f/log2f are libm-dependent to 1 ulp off powers of two
+                np.testing.assert_allclose([float(x) for x in list(g.scale)[:nl]], geo.scales, rtol=3e-7)
+
+
+def test_invalid_arguments_return_errors(L):
+    h = L.lib()
+    bad = L.GridCfg(4, 16, 2, 19, 16, 2.0)
+    g = L.GridGeometry()
+    assert h.immoco_grid_geometry_query(C.byref(bad), C.byref(g)) == -1
+    assert "dims" in L.last_error()
+    with pytest.raises(L.ImmocoError):
+        L.check(h.immoco_fft2c(None, None, 1, 0, 4, 0, None), "fft2c")
+    with pytest.raises(L.ImmocoError):
+        L.mlp_cfg(32, 2, {"otype": "FullyFusedMLP", "activation": "Sine", "n_neurons": 64})
+    with pytest.raises(L.ImmocoError):
+        L.grid_cfg(2, {"otype": "Frequency"})
+    cfg = L.SolverCfg(321, 320, 2, L.grid_cfg(2, {}), L.grid_cfg(3, {}), L.mlp_cfg(32, 2, {"otype": "CutlassMLP", "n_neurons": 256}),
+                      L.mlp_cfg(32, 2, {"otype": "FullyFusedMLP", "activation": "Tanh", "n_neurons": 64}), 1)
+    out = C.c_void_p()
+    assert h.immoco_solver_create(C.byref(cfg), C.byref(out)) == -1 and "even" in L.last_error()
+
+
+def test_cpu_tensors_are_refused(L):
+    import miccai24_immoco_amd as pkg
+    with pytest.raises(L.ImmocoError):
+        pkg.FFT(torch.zeros(4, 4, dtype=torch.complex64))
+    with pytest.raises(L.ImmocoError):
+        pkg.GradientEntropyLoss()(torch.zeros(4, 4, dtype=torch.complex64))
+    with pytest.raises(L.ImmocoError):
+        pkg.extract_movement_groups(torch.zeros(8, dtype=torch.bool))
+    with pytest.raises(L.ImmocoError):
+        pkg.imcoco_motion_correction(torch.zeros(16, 16, dtype=torch.complex64), torch.zeros(1, 16, 16, dtype=torch.long))
+
+
+def test_missing_library_fails_loudly(L, tmp_path):
+    with pytest.raises(L.ImmocoError):
+        L.load(str(tmp_path / "libimmoco_hip.so"))
+
+
+def test_lambda_schedule_host_logic():
+    from miccai24_immoco_amd.models.immoco import lambda_schedule
+    from oracle import immoco_oracle as orc
+    for iters in (10, 50, 200, 3000):
+        assert lambda_schedule(iters, 1e-2) == orc.lambda_schedule(iters, 1e-2)
+    with pytest.raises(ZeroDivisionError):
+        lambda_schedule(9, 1e-2)
+    d = lambda_schedule(200, 1e-2, rule="downstream")
+    assert d[91] == 0.5e-2 and d[90] == 1e-2 and d[101] == 0.25e-2
+
+
+def test_make_grids_matches_golden(golden):
+    from miccai24_immoco_amd.models.immoco import make_grids
+    g = golden("ops")
+    assert np.array_equal(make_grids((2, 3, 4)).numpy(), g["make_grids_2_3_4"])
+    assert np.array_equal(make_grids((1, 3, 5)).numpy(), g["make_grids_1_3_5"])
+
+
+def test_synth_motion_simulation_matches_golden(golden):
+    from miccai24_immoco_amd import synth
+    g = golden("motion_sim")
+    for tag in ("s32", "s64"):
+        torch.manual_seed(int(g[f"{tag}_seed"]))
+        k, m, r, t = synth.motion_simulation2D(torch.from_numpy(g[f"{tag}_img"]).clone(), int(g[f"{tag}_nm"]))
+        assert np.array_equal(m[0].numpy().astype(np.uint8), g[f"{tag}_mask_row0"])
+        np.testing.assert_allclose(k.numpy(), g[f"{tag}_ksp"], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(r.numpy(), g[f"{tag}_rot"]) and np.array_equal(t.numpy(), g[f"{tag}_tr"])
