@@ -82,6 +82,21 @@ __device__ __forceinline__ uint32_t grid_index(const uint32_t (&c)[D], uint32_t 
   return pow2 ? (idx & (size - 1u)) : (idx % size);
 }
 
+// Un-contracted fp32 ops (hipcc's __fmul_rn/__fadd_rn are plain operators and get fused into
+// FMAs under the default -ffp-contract=fast): used where bit-identity with the oracle matters.
+__device__ __forceinline__ float mul_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // PCG output hash shared with oracle.pcg_hash_u32.
 __host__ __device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
   uint32_t state = x * 747796405u + 2891336453u;

@@ -95,13 +95,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
     for (int d = 0; d < D; ++d) {
       const bool hi = (corner >> d) & 1;
       c[d] = cell[d] + (hi ? 1u : 0u);
-      w = __fmul_rn(w, hi ? fr[d] : __fsub_rn(1.0f, fr[d]));
+      w = mul_nc(w, hi ? fr[d] : sub_nc(1.0f, fr[d]));
     }
     const float2 v = tab[grid_index<D>(c, size, res, hashed, pow2)];
     // separate mul/add (no contraction): bit-identical to the fp32 oracle
-    const float t0 = __fmul_rn(v.x, w), t1 = __fmul_rn(v.y, w);
-    a0 = corner == 0 ? t0 : __fadd_rn(a0, t0);
-    a1 = corner == 0 ? t1 : __fadd_rn(a1, t1);
+    const float t0 = mul_nc(v.x, w), t1 = mul_nc(v.y, w);
+    a0 = corner == 0 ? t0 : add_nc(a0, t0);
+    a1 = corner == 0 ? t1 : add_nc(a1, t1);
   }
   *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = make_float2(a0, a1);
 }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void init_uniform_kernel(float* __restrict__ o
   if (i >= n) return;
   const uint32_t h = pcg_hash((uint32_t)i + key);
   const float u = (float)(h >> 8) * 5.9604644775390625e-08f;  // 2^-24
-  out[i] = __fadd_rn(lo, __fmul_rn(u, span));
+  out[i] = add_nc(lo, mul_nc(u, span));
 }
 
 int launch_init_uniform(float* out, int64_t n, uint32_t seed, uint32_t stream_id, float lo, float hi,
