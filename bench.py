@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3000, help="Adam iterations per slice (BASELINE: 3000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--grad-parts", type=int, default=0, help="transposed-index parts (0 = library default)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -126,11 +127,11 @@ def main():
         masks = pkg.extract_movement_groups(s["lines"].to(dev), make_list=True)
         slices.append({"kspace": s["kspace"].to(dev), "masks": masks, "gt": s["gt"]})
     nM = int(slices[0]["masks"].shape[0])
-    get_solver(dev, H, W, nM, not args.no_graph)      # plans + workspace (one-off, like FFT plan creation)
+    get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts)      # plans + workspace (one-off, like FFT plan creation)
 
     def solve(sl):
         return pkg.imcoco_motion_correction(sl["kspace"], sl["masks"], iters=args.iters, learning_rate=1e-2,
-                                            lambda_ge=1e-2, use_graph=not args.no_graph)
+                                            lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts)
 
     def barrier():
         if world > 1:
@@ -160,7 +161,7 @@ def main():
         from miccai24_immoco_amd.utils.data_utils import IFFT
         psnr_in = [crop_psnr(IFFT(slices[Wm + j]["kspace"]).abs().cpu(), slices[Wm + j]["gt"].abs()) for j in range(K)]
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
-        solver = get_solver(dev, H, W, nM, not args.no_graph)
+        solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts)
         sl = slices[0]
         k = sl["kspace"]
         kin = k / k.abs().max() * 16000

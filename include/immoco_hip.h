@@ -82,6 +82,22 @@ int immoco_hashgrid_bwd(const immoco_grid_cfg* cfg, const float* coords, int64_t
                         const float* denc, int64_t enc_point_stride, int64_t enc_level_stride,
                         float* dtable, void* stream);
 
+/* ---- atomic-free hash-grid backward for a FIXED lattice (the reference always queries
+ *      linspace lattices, immoco.py:48-53,72-80): a transposed index (table slot -> list
+ *      of contributing lattice points) is built once, then every backward is a gather.
+ *  dims 3: point (m,row,col) has coordinates (ax0[m], ax1[row], ax2[col]) (make_grids order);
+ *  dims 2: nM must be 1, point (row,col) has coordinates (ax0[col], ax1[row]) (identy_grid
+ *          order), ax2 unused.  The axis arrays (device) must outlive the plan, unchanged. */
+typedef struct immoco_grid_plan* immoco_grid_plan_t;
+int immoco_grid_plan_create(const immoco_grid_cfg* cfg, int32_t nM, int32_t H, int32_t W,
+                            const float* ax0, const float* ax1, const float* ax2,
+                            immoco_grid_plan_t* out, void* stream);
+int immoco_grid_plan_destroy(immoco_grid_plan_t p);
+int64_t immoco_grid_plan_bytes(immoco_grid_plan_t p);
+/* denc: level-major [n_levels][nM*H*W][2]; dtable [n_entries][2] ACCUMULATES. */
+int immoco_grid_plan_bwd(immoco_grid_plan_t p, const float* denc_level_major, float* dtable,
+                         void* stream);
+
 /* ---- INR: bias-free one-hidden-layer MLP (tcnn CutlassMLP / FullyFusedMLP) */
 /* w1 [n_hidden][n_in], w2 [n_out_padded][n_hidden] row-major; out [n][n_out]. */
 int immoco_mlp_fwd(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
@@ -156,8 +172,12 @@ typedef struct immoco_solver_cfg {
   int32_t H, W, nM;
   immoco_grid_cfg image_grid, motion_grid;
   immoco_mlp_cfg image_mlp, motion_mlp;
-  int32_t use_graph; /* 1: capture one iteration in a hipGraph and replay it */
-  int32_t reserved[7];
+  int32_t use_graph;      /* 1: capture one iteration in a hipGraph and replay it */
+  int32_t atomic_scatter; /* 1: hash-grid backward by global float atomics (slow reference path
+                             kept for A/B measurements); 0: transposed-index gather (default) */
+  int32_t grad_parts;     /* point-range parts of the motion grid's transposed index (1, 2, 4 or 8;
+                             0 = default 4): each XCD keeps a 8/parts MB slice of dL/denc in its L2 */
+  int32_t reserved[5];
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;
@@ -169,11 +189,15 @@ int immoco_solver_destroy(immoco_solver_t s);
 int64_t immoco_solver_workspace_bytes(immoco_solver_t s);
 int64_t immoco_solver_n_params(immoco_solver_t s, int32_t which /*0 image, 1 motion*/);
 
+/* Sets the coordinate lattices once per solver: xs[W], ys[H], ms[nM] fp32 (device) = the
+ * reference's linspace(-1,1,.) lattices (immoco.py:48-53,72-80), computed by the caller.
+ * Copies them and builds the transposed hash-grid indices (synchronous). */
+int immoco_solver_set_lattice(immoco_solver_t s, const float* xs, const float* ys, const float* ms,
+                              void* stream);
+
 /* Runs `iters` Adam iterations (immoco.py:164-181) on one slice.
  *  kspace_in  [H,W] c64, ALREADY normalised (immoco_normalize_kspace);
  *  col_group  [W] int32 (0 = FFT(image) column, m>=1 = FFT(warp_m) column);
- *  axis coords: xs[W], ys[H], ms[nM] fp32 = the reference's linspace(-1,1,.)
- *               lattices (immoco.py:48-53,72-80), computed by the caller;
  *  params_*   flat fp32 [W1|W2|table] (tcnn order), updated in place;
  *  adam_*     [2*n_params] fp32 (m then v), caller-zeroed for a fresh solve;
  *  lambda_sched [host][iters] GE weight used at iteration j (immoco.py:180-181);
@@ -181,21 +205,20 @@ int64_t immoco_solver_n_params(immoco_solver_t s, int32_t which /*0 image, 1 mot
  *               before the final Adam step (immoco.py:203-206);
  *  loss_hist  device [iters] fp32 or NULL: total loss per iteration. */
 int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
-                        const float* xs, const float* ys, const float* ms, float* params_image,
+                        float* params_image,
                         float* params_motion, float* adam_image, float* adam_motion, int32_t iters,
                         float lr, const float* lambda_sched /*[host]*/, int32_t step0,
                         float* out_image, float* out_kspace, float* loss_hist, void* stream);
 
 /* One forward pass only (IMMoCo.forward, immoco.py:82-113). */
-int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* xs,
-                          const float* ys, const float* ms, const float* params_image,
+int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* params_image,
                           const float* params_motion, float* out_image, float* out_kspace,
                           void* stream);
 
 /* Times every kernel of the iteration with HIP events on the solver's stream:
  * `reps` eager iterations (parameters / Adam state advance as in a real solve). */
 int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
-                          const float* xs, const float* ys, const float* ms, float* params_image,
+                          float* params_image,
                           float* params_motion, float* adam_image, float* adam_motion, int32_t reps,
                           float lr, float lambda_ge, void* stream);
 /* Average per-kernel device time (ms) of the last immoco_solver_profile call, for

@@ -43,7 +43,8 @@ class SolverCfg(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("nM", C.c_int32),
                 ("image_grid", GridCfg), ("motion_grid", GridCfg),
                 ("image_mlp", MlpCfg), ("motion_mlp", MlpCfg),
-                ("use_graph", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("use_graph", C.c_int32), ("atomic_scatter", C.c_int32), ("grad_parts", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 _P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
@@ -75,10 +76,15 @@ PROTOTYPES = {
     "immoco_solver_destroy": (C.c_int, [_P]),
     "immoco_solver_workspace_bytes": (C.c_int64, [_P]),
     "immoco_solver_n_params": (C.c_int64, [_P, _I32]),
-    "immoco_solver_solve": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _F,
+    "immoco_solver_set_lattice": (C.c_int, [_P, _P, _P, _P, _P]),
+    "immoco_solver_solve": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _F,
                                       C.POINTER(C.c_float), _I32, _P, _P, _P, _P]),
-    "immoco_solver_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "immoco_solver_profile": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _F, _F, _P]),
+    "immoco_solver_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "immoco_solver_profile": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _F, _F, _P]),
+    "immoco_grid_plan_create": (C.c_int, [_GP, _I32, _I32, _I32, _P, _P, _P, C.POINTER(C.c_void_p), _P]),
+    "immoco_grid_plan_destroy": (C.c_int, [_P]),
+    "immoco_grid_plan_bytes": (C.c_int64, [_P]),
+    "immoco_grid_plan_bwd": (C.c_int, [_P, _P, _P, _P]),
     "immoco_solver_phase_times": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _I32]),
     "immoco_solver_graph_active": (C.c_int, [_P]),
 }

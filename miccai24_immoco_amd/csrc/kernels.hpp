@@ -62,8 +62,20 @@ int launch_image_grad_init(const float* image, const float* adj_slot0, int H, in
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
                 float beta1, float beta2, float eps, hipStream_t st);
 // device-scheduled variant: scalars read from sched[2*it], it = *iter_dev; g zeroed after use
-int launch_adam_sched(float* p, float* g, float* m, float* v, int64_t n, const float* sched,
-                      const int32_t* iter_dev, float beta1, float beta2, float eps, hipStream_t st);
+// g: n_gparts partial gradient buffers, g_stride floats apart; their sum is the gradient
+int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n,
+                      const float* sched, const int32_t* iter_dev, float beta1, float beta2, float eps,
+                      hipStream_t st);
+
+// csr.hip — atomic-free hash-grid backward for fixed lattices
+struct CsrPlan;
+int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* axes, const int32_t* axn,
+                   int n_parts, CsrPlan** out, hipStream_t st);
+void csr_plan_free(CsrPlan* p);
+int64_t csr_plan_bytes(const CsrPlan* p);
+int csr_plan_parts(const CsrPlan* p);
+int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,
+                   int zeroed, hipStream_t st);
 
 // masks.hip
 int launch_extract_groups(const uint8_t* lines, int n, int32_t* col_group, int32_t* n_groups, hipStream_t st);

@@ -37,6 +37,11 @@ struct immoco_solver {
   float *enc_img = nullptr, *enc_mot = nullptr, *image = nullptr, *o_mot = nullptr, *t_mot = nullptr;
   float *fftbuf = nullptr, *dimage = nullptr, *grad_img = nullptr, *grad_mot = nullptr, *kout = nullptr;
   float *sched = nullptr, *lambda_dev = nullptr;
+  float *xs = nullptr, *ys = nullptr, *ms = nullptr;  // solver-owned copies of the lattices
+  CsrPlan *plan_img = nullptr, *plan_mot = nullptr;
+  bool lattice_set = false;
+  int mot_parts = 1;            // partial gradient tables of the motion INR
+  int64_t mot_gstride = 0;      // floats between them (n_params_mot rounded up to 4)
   int32_t* iter_dev = nullptr;
   int32_t sched_cap = 0;
   int64_t bytes = 0;
@@ -63,7 +68,6 @@ int dev_alloc(immoco_solver* s, T** p, int64_t count) {
 struct Bind {
   const float* kin;
   const int32_t* col_group;
-  const float *xs, *ys, *ms;
   float *p_img, *p_mot, *a_img, *a_mot;
   float* loss_hist;
 };
@@ -75,13 +79,13 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   const int64_t P = s->P, NP = s->NP;
   Lattice li{}, lm{};
   // image INR: identy_grid.view(-1,2) = (x = xs[col], y = ys[row])  (immoco.py:72-76,85)
-  li.axis[0] = b.xs; li.n[0] = W; li.stride[0] = 1;
-  li.axis[1] = b.ys; li.n[1] = H; li.stride[1] = W;
-  li.axis[2] = b.xs; li.n[2] = 1; li.stride[2] = 1;
+  li.axis[0] = s->xs; li.n[0] = W; li.stride[0] = 1;
+  li.axis[1] = s->ys; li.n[1] = H; li.stride[1] = W;
+  li.axis[2] = s->xs; li.n[2] = 1; li.stride[2] = 1;
   // motion INR: make_grids((nM,H,W)) = (m, row, col)  (immoco.py:48-53,78-80,93)
-  lm.axis[0] = b.ms; lm.n[0] = nM; lm.stride[0] = H * W;
-  lm.axis[1] = b.ys; lm.n[1] = H; lm.stride[1] = W;
-  lm.axis[2] = b.xs; lm.n[2] = W; lm.stride[2] = 1;
+  lm.axis[0] = s->ms; lm.n[0] = nM; lm.stride[0] = H * W;
+  lm.axis[1] = s->ys; lm.n[1] = H; lm.stride[1] = W;
+  lm.axis[2] = s->xs; lm.n[2] = W; lm.stride[2] = 1;
   float* w1i = b.p_img;
   float* w2i = w1i + (int64_t)c.image_mlp.n_hidden * c.image_mlp.n_in;
   float* tabi = b.p_img + s->n_w_img;
@@ -112,7 +116,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
                   }});
     st.push_back({"motion_warp_fwd", [=](hipStream_t q) {
-                    return launch_motion_warp_fwd(s->image, s->o_mot, b.xs, b.ys, nM, H, W, s->t_mot, slot1, q);
+                    return launch_motion_warp_fwd(s->image, s->o_mot, s->xs, s->ys, nM, H, W, s->t_mot, slot1, q);
                   }});
   }
   st.push_back({"fft_fwd", [=](hipStream_t q) { return fft_exec_inplace(s->fftbuf, nM + 1, H, W, false, q); }});
@@ -128,7 +132,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                 }});
   if (nM > 0) {
     st.push_back({"motion_warp_bwd", [=](hipStream_t q) {
-                    return launch_motion_warp_bwd(s->image, s->t_mot, b.xs, b.ys, slot1, nM, H, W, s->dimage,
+                    return launch_motion_warp_bwd(s->image, s->t_mot, s->xs, s->ys, slot1, nM, H, W, s->dimage,
                                                   s->o_mot, q);
                   }});
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
@@ -136,6 +140,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                           s->enc_mot, g_w1m, g_w2m, q);
                   }});
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
+                    if (s->plan_mot) return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q);
                     return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
                   }});
   }
@@ -144,16 +149,18 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                         g_w1i, g_w2i, q);
                 }});
   st.push_back({"image_encode_bwd", [=](hipStream_t q) {
+                  if (s->plan_img) return launch_csr_bwd(s->plan_img, s->enc_img, g_tabi, 0, 1, q);
                   return launch_hashgrid_bwd(s->lv_img, nullptr, &li, P, s->enc_img, 2, 2 * P, g_tabi, q);
                 }});
   // optimizer param-group order of the reference: motion first, then image (immoco.py:149-154)
   if (nM > 0)
     st.push_back({"adam_motion", [=](hipStream_t q) {
-                    return launch_adam_sched(b.p_mot, s->grad_mot, b.a_mot, b.a_mot + s->n_params_mot,
-                                             s->n_params_mot, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
+                    return launch_adam_sched(b.p_mot, s->grad_mot, s->plan_mot ? s->mot_parts : 1, s->mot_gstride,
+                                             b.a_mot, b.a_mot + s->n_params_mot, s->n_params_mot, s->sched,
+                                             s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
                   }});
   st.push_back({"adam_image", [=](hipStream_t q) {
-                  return launch_adam_sched(b.p_img, s->grad_img, b.a_img, b.a_img + s->n_params_img,
+                  return launch_adam_sched(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
                                            s->n_params_img, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
                 }});
   st.push_back({"tick", [=](hipStream_t q) {
@@ -239,14 +246,19 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   A(dimage, 2 * s->P)
   A(kout, 2 * s->P)
   A(grad_img, s->n_params_img)
-  A(grad_mot, s->n_params_mot)
+  s->mot_parts = cfg->atomic_scatter ? 1 : (cfg->grad_parts > 0 ? cfg->grad_parts : 4);
+  s->mot_gstride = (s->n_params_mot + 3) / 4 * 4;
+  A(grad_mot, s->mot_gstride * s->mot_parts)
   A(iter_dev, 4)
+  A(xs, cfg->W)
+  A(ys, cfg->H)
+  A(ms, cfg->nM > 0 ? cfg->nM : 1)
 #undef A
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(s->grad_img, 0, (size_t)s->n_params_img * 4);
-  if (e == hipSuccess) e = hipMemset(s->grad_mot, 0, (size_t)s->n_params_mot * 4);
+  if (e == hipSuccess) e = hipMemset(s->grad_mot, 0, (size_t)s->mot_gstride * s->mot_parts * 4);
   if (e != hipSuccess) {
     set_error("solver_create: %s", hipGetErrorString(e));
     immoco_solver_destroy(s);
@@ -265,7 +277,9 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
 extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   if (!s) return IMMOCO_OK;
   if (s->gexec) hipGraphExecDestroy(s->gexec);
-  float* bufs[] = {s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
+  csr_plan_free(s->plan_img);
+  csr_plan_free(s->plan_mot);
+  float* bufs[] = {s->xs, s->ys, s->ms, s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
                    s->kout,    s->grad_img, s->grad_mot, s->sched, s->lambda_dev};
   for (float* b : bufs)
     if (b) hipFree(b);
@@ -277,21 +291,55 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   return IMMOCO_OK;
 }
 
-extern "C" int64_t immoco_solver_workspace_bytes(immoco_solver_t s) { return s ? s->bytes : 0; }
+extern "C" int64_t immoco_solver_workspace_bytes(immoco_solver_t s) {
+  return s ? s->bytes + csr_plan_bytes(s->plan_img) + csr_plan_bytes(s->plan_mot) : 0;
+}
 
 extern "C" int64_t immoco_solver_n_params(immoco_solver_t s, int32_t which) {
   if (!s) return 0;
   return which == 0 ? s->n_params_img : s->n_params_mot;
 }
 
+extern "C" int immoco_solver_set_lattice(immoco_solver_t s, const float* xs, const float* ys, const float* ms,
+                                         void* stream) {
+  IMMOCO_REQUIRE(s && xs && ys && (s->cfg.nM == 0 || ms), "solver_set_lattice: NULL argument");
+  hipStream_t caller = as_stream(stream);
+  const immoco_solver_cfg& c = s->cfg;
+  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->xs, xs, (size_t)c.W * 4, hipMemcpyDeviceToDevice, caller));
+  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->ys, ys, (size_t)c.H * 4, hipMemcpyDeviceToDevice, caller));
+  if (c.nM > 0) IMMOCO_CHECK_HIP(hipMemcpyAsync(s->ms, ms, (size_t)c.nM * 4, hipMemcpyDeviceToDevice, caller));
+  IMMOCO_CHECK_HIP(hipStreamSynchronize(caller));
+  csr_plan_free(s->plan_img);
+  csr_plan_free(s->plan_mot);
+  s->plan_img = s->plan_mot = nullptr;
+  if (s->gexec) {  // plans are baked into a captured graph
+    hipGraphExecDestroy(s->gexec);
+    s->gexec = nullptr;
+  }
+  if (!c.atomic_scatter) {
+    int rc;
+    const float* ax2[3] = {s->xs, s->ys, nullptr};
+    const int32_t n2[3] = {c.W, c.H, 0};
+    if ((rc = csr_plan_build(s->lv_img, 1, c.H, c.W, ax2, n2, 1, &s->plan_img, s->stream))) return rc;
+    if (c.nM > 0) {
+      const float* ax3[3] = {s->ms, s->ys, s->xs};
+      const int32_t n3[3] = {c.nM, c.H, c.W};
+      if ((rc = csr_plan_build(s->lv_mot, c.nM, c.H, c.W, ax3, n3, s->mot_parts, &s->plan_mot, s->stream))) return rc;
+    }
+  }
+  s->lattice_set = true;
+  return IMMOCO_OK;
+}
+
 extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
-                                   const float* xs, const float* ys, const float* ms, float* params_image,
+                                   float* params_image,
                                    float* params_motion, float* adam_image, float* adam_motion, int32_t iters,
                                    float lr, const float* lambda_sched, int32_t step0, float* out_image,
                                    float* out_kspace, float* loss_hist, void* stream) {
   IMMOCO_REQUIRE(s, "solver_solve: NULL solver");
-  IMMOCO_REQUIRE(kspace_in && col_group && xs && ys && params_image && adam_image, "solver_solve: NULL buffer");
-  IMMOCO_REQUIRE(s->cfg.nM == 0 || (ms && params_motion && adam_motion), "solver_solve: NULL motion buffer");
+  IMMOCO_REQUIRE(s->lattice_set, "solver_solve: call immoco_solver_set_lattice first");
+  IMMOCO_REQUIRE(kspace_in && col_group && params_image && adam_image, "solver_solve: NULL buffer");
+  IMMOCO_REQUIRE(s->cfg.nM == 0 || (params_motion && adam_motion), "solver_solve: NULL motion buffer");
   IMMOCO_REQUIRE(iters >= 1 && lambda_sched && step0 >= 0, "solver_solve: bad iters/schedule");
   hipStream_t caller = as_stream(stream);
   int rc;
@@ -312,12 +360,12 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   if (loss_hist) IMMOCO_CHECK_HIP(hipMemsetAsync(loss_hist, 0, (size_t)iters * 4, q));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
 
-  Bind b{kspace_in, col_group, xs, ys, ms, params_image, params_motion, adam_image, adam_motion, loss_hist};
+  Bind b{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
   std::vector<Step> steps = build_steps(s, b, true);
   s->graph_active = 0;
   if (s->cfg.use_graph) {
-    std::vector<const void*> key = {kspace_in, col_group, xs,          ys,          ms,       params_image,
-                                    params_motion, adam_image, adam_motion, loss_hist, s->sched};
+    std::vector<const void*> key = {kspace_in,  col_group,   params_image, params_motion,
+                                    adam_image, adam_motion, loss_hist,    s->sched};
     if (!s->gexec || key != s->gkey) {
       if (s->gexec) {
         hipGraphExecDestroy(s->gexec);
@@ -351,18 +399,19 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   return leave(s, caller);
 }
 
-extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* xs, const float* ys,
-                                     const float* ms, const float* params_image, const float* params_motion,
-                                     float* out_image, float* out_kspace, void* stream) {
-  IMMOCO_REQUIRE(s && col_group && xs && ys && params_image, "solver_forward: NULL argument");
-  IMMOCO_REQUIRE(s->cfg.nM == 0 || (ms && params_motion), "solver_forward: NULL motion buffer");
+extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* params_image,
+                                     const float* params_motion, float* out_image, float* out_kspace,
+                                     void* stream) {
+  IMMOCO_REQUIRE(s && col_group && params_image, "solver_forward: NULL argument");
+  IMMOCO_REQUIRE(s->lattice_set, "solver_forward: call immoco_solver_set_lattice first");
+  IMMOCO_REQUIRE(s->cfg.nM == 0 || params_motion, "solver_forward: NULL motion buffer");
   hipStream_t caller = as_stream(stream);
   int rc;
   if ((rc = enter(s, caller))) return rc;
   hipStream_t q = s->stream;
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   // kin only feeds the (unused) residual here: point it at kout itself
-  Bind b{s->kout, col_group, xs, ys, ms, const_cast<float*>(params_image), const_cast<float*>(params_motion),
+  Bind b{s->kout, col_group, const_cast<float*>(params_image), const_cast<float*>(params_motion),
          nullptr, nullptr, nullptr};
   std::vector<Step> steps = build_steps(s, b, false);
   if ((rc = run_steps(steps, q))) return rc;
@@ -374,10 +423,10 @@ extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group
 // Times every step of one iteration with HIP events on the solver's own stream (eager launches,
 // `reps` repetitions, parameters and Adam state are advanced like in a real solve).
 extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
-                                     const float* xs, const float* ys, const float* ms, float* params_image,
+                                     float* params_image,
                                      float* params_motion, float* adam_image, float* adam_motion, int32_t reps,
                                      float lr, float lambda_ge, void* stream) {
-  IMMOCO_REQUIRE(s && reps >= 1, "solver_profile: bad argument");
+  IMMOCO_REQUIRE(s && reps >= 1 && s->lattice_set, "solver_profile: bad argument / lattice not set");
   hipStream_t caller = as_stream(stream);
   int rc;
   if ((rc = ensure_sched(s, reps))) return rc;
@@ -393,7 +442,7 @@ extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, 
   IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));
-  Bind b{kspace_in, col_group, xs, ys, ms, params_image, params_motion, adam_image, adam_motion, nullptr};
+  Bind b{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, nullptr};
   std::vector<Step> steps = build_steps(s, b, true);
   const size_t n = steps.size();
   std::vector<hipEvent_t> ev((n + 1) * (size_t)reps);

@@ -146,14 +146,14 @@ class IMMoCo(nn.Module):
 class _SolverHandle:
     """RAII wrapper of immoco_solver_t; cached per (device, H, W, nM)."""
 
-    def __init__(self, device, H, W, nM, use_graph=True):
+    def __init__(self, device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0):
         self.device, self.H, self.W, self.nM = device, H, W, nM
         self.image_grid = L.grid_cfg(2, encoding_config)
         self.motion_grid = L.grid_cfg(3, encoding_config)
         self.image_mlp = L.mlp_cfg(32, 2, network_config)
         self.motion_mlp = L.mlp_cfg(32, 2, mot_network_config)
         cfg = L.SolverCfg(H, W, nM, self.image_grid, self.motion_grid, self.image_mlp, self.motion_mlp,
-                          1 if use_graph else 0)
+                          1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts))
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(L.lib().immoco_solver_create(C.byref(cfg), C.byref(self.handle)), "solver_create")
@@ -163,6 +163,9 @@ class _SolverHandle:
         self.xs = torch.linspace(-1, 1, W, device=device)
         self.ys = torch.linspace(-1, 1, H, device=device)
         self.ms = torch.linspace(-1, 1, max(nM, 1), device=device)
+        with torch.cuda.device(device):
+            L.check(L.lib().immoco_solver_set_lattice(self.handle, L.ptr(self.xs), L.ptr(self.ys), L.ptr(self.ms),
+                                                      L.stream_ptr()), "solver_set_lattice")
 
     @property
     def workspace_bytes(self):
@@ -199,7 +202,7 @@ class _SolverHandle:
         lam = (C.c_float * iters)(*[float(v) for v in lambdas])
         with torch.cuda.device(dev):
             L.check(L.lib().immoco_solver_solve(
-                self.handle, L.ptr(kspace_norm), L.ptr(col_group), L.ptr(self.xs), L.ptr(self.ys), L.ptr(self.ms),
+                self.handle, L.ptr(kspace_norm), L.ptr(col_group),
                 L.ptr(p_img), L.ptr(p_mot), L.ptr(a_img), L.ptr(a_mot), iters, float(lr), lam, int(step0),
                 L.ptr(out_img), L.ptr(out_k), L.ptr(loss), L.stream_ptr()), "solver_solve")
         return out_img, out_k, loss
@@ -208,15 +211,14 @@ class _SolverHandle:
         out_img = torch.empty((self.H, self.W), device=self.device, dtype=torch.complex64)
         out_k = torch.empty((self.H, self.W), device=self.device, dtype=torch.complex64)
         with torch.cuda.device(self.device):
-            L.check(L.lib().immoco_solver_forward(self.handle, L.ptr(col_group), L.ptr(self.xs), L.ptr(self.ys),
-                                                  L.ptr(self.ms), L.ptr(p_img), L.ptr(p_mot), L.ptr(out_img),
-                                                  L.ptr(out_k), L.stream_ptr()), "solver_forward")
+            L.check(L.lib().immoco_solver_forward(self.handle, L.ptr(col_group), L.ptr(p_img), L.ptr(p_mot),
+                                                  L.ptr(out_img), L.ptr(out_k), L.stream_ptr()), "solver_forward")
         return out_k, out_img
 
     def profile(self, kspace_norm, col_group, p_img, p_mot, a_img, a_mot, reps=5, lr=1e-2, lambda_ge=1e-2):
         with torch.cuda.device(self.device):
             L.check(L.lib().immoco_solver_profile(
-                self.handle, L.ptr(kspace_norm), L.ptr(col_group), L.ptr(self.xs), L.ptr(self.ys), L.ptr(self.ms),
+                self.handle, L.ptr(kspace_norm), L.ptr(col_group),
                 L.ptr(p_img), L.ptr(p_mot), L.ptr(a_img), L.ptr(a_mot), reps, float(lr), float(lambda_ge),
                 L.stream_ptr()), "solver_profile")
             torch.cuda.synchronize(self.device)
@@ -233,14 +235,14 @@ class _SolverHandle:
 _SOLVERS = {}
 
 
-def get_solver(device, H, W, nM, use_graph=True) -> _SolverHandle:
+def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0) -> _SolverHandle:
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    key = (device.index, H, W, nM, bool(use_graph))
+    key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts))
     s = _SOLVERS.get(key)
     if s is None:
-        s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph)
+        s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts)
     return s
 
 
@@ -264,7 +266,7 @@ def lambda_schedule(iters, lambda_ge, rule="immoco"):
 
 def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2, debug=False,
                              *, seed=1337, norm_scale=16000.0, lambda_rule="immoco", return_loss=False,
-                             use_graph=True):
+                             use_graph=True, atomic_scatter=False, grad_parts=0):
     """IM-MoCo per-slice solve (immoco.py:116-206).
 
     Args mirror the reference: ``kspace_corr`` [H, W] complex (any device), ``masks`` [nM, H, W]
@@ -277,7 +279,7 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
     dev = masks.device
     nM, H, W = masks.shape
     lambdas = lambda_schedule(iters, lambda_ge, lambda_rule)   # raises ZeroDivisionError like the reference
-    solver = get_solver(dev, H, W, nM, use_graph)
+    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts)
     k = kspace_corr.to(dev).to(torch.complex64).contiguous()
     if k.shape != (H, W):
         raise L.ImmocoError(f"kspace_corr shape {tuple(k.shape)} does not match masks {(H, W)}")

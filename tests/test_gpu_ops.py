@@ -445,3 +445,56 @@ def test_lambda_schedule_quirk_and_errors(env):
     with pytest.raises(ZeroDivisionError):
         pkg.imcoco_motion_correction(torch.zeros(16, 16, dtype=torch.complex64).cuda(),
                                      torch.zeros(1, 16, 16, dtype=torch.long).cuda(), iters=9)
+
+
+# ------------------------------------------------- atomic-free (transposed index) backward
+@pytest.mark.parametrize("dims", [2, 3])
+def test_grid_plan_bwd_matches_atomic_and_oracle(env, dims):
+    pkg, L, orc = env
+    nM, H, W = (3, 20, 24) if dims == 3 else (1, 36, 28)
+    xs, ys, ms = (torch.linspace(-1, 1, n) for n in (W, H, max(nM, 1)))
+    if dims == 3:
+        coords = orc.make_grids((nM, H, W))                       # (m, row, col)
+        axes = (ms, ys, xs)
+    else:
+        coords = orc.identity_grid(H, W).view(-1, 2)              # (x = col, y = row)
+        axes = (xs, ys, xs)
+    n = coords.shape[0]
+    geo = orc.geometry_from_config(dims, orc.encoding_config)
+    g = torch.Generator().manual_seed(11 + dims)
+    denc = torch.randn(n, 32, generator=g)
+    t = torch.zeros(geo.n_entries, 2, requires_grad=True)
+    (orc.HashGridPlan(coords, geo).encode(t) * denc).sum().backward()
+    cfg = L.grid_cfg(dims, pkg.encoding_config)
+    ax = [a.cuda() for a in axes]
+    plan = C.c_void_p()
+    st = L.stream_ptr()
+    L.check(L.lib().immoco_grid_plan_create(C.byref(cfg), nM, H, W, L.ptr(ax[0]), L.ptr(ax[1]), L.ptr(ax[2]),
+                                            C.byref(plan), st), "grid_plan_create")
+    try:
+        assert L.lib().immoco_grid_plan_bytes(plan) >= n * 16 * (1 << dims) * 4
+        d_lm = denc.view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()        # level-major
+        dt = torch.zeros(geo.n_entries, 2, device="cuda")
+        L.check(L.lib().immoco_grid_plan_bwd(plan, L.ptr(d_lm), L.ptr(dt), st), "grid_plan_bwd")
+        da = torch.zeros(geo.n_entries, 2, device="cuda")
+        cd = coords.cuda().contiguous()
+        L.check(L.lib().immoco_hashgrid_bwd(C.byref(cfg), L.ptr(cd), n, L.ptr(d_lm), 2, 2 * n, L.ptr(da), st))
+        s = t.grad.abs().max()
+        assert (dt.cpu() - t.grad).abs().max() <= 1e-5 * s
+        assert (dt - da).abs().max().item() <= 1e-5 * s
+        # accumulates (does not overwrite)
+        L.check(L.lib().immoco_grid_plan_bwd(plan, L.ptr(d_lm), L.ptr(dt), st), "grid_plan_bwd")
+        assert (dt.cpu() - 2 * t.grad).abs().max() <= 2e-5 * s
+    finally:
+        L.lib().immoco_grid_plan_destroy(plan)
+
+
+def test_solver_csr_vs_atomic_scatter(env, golden):
+    """The transposed-index backward and the atomic scatter give the same first iterations."""
+    pkg, L, orc = env
+    g, H, masks = _golden_case(golden, "c48")
+    ksp = torch.from_numpy(g["c48_ksp"]).cuda()
+    _, _, l0 = pkg.imcoco_motion_correction(ksp, masks.cuda(), iters=12, return_loss=True, atomic_scatter=False)
+    _, _, l1 = pkg.imcoco_motion_correction(ksp, masks.cuda(), iters=12, return_loss=True, atomic_scatter=True)
+    np.testing.assert_allclose(l0.cpu().numpy()[:5], l1.cpu().numpy()[:5], rtol=1e-3)
+    np.testing.assert_allclose(l0.cpu().numpy(), l1.cpu().numpy(), rtol=0.1)
