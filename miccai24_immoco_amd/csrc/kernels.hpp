@@ -27,6 +27,13 @@ int launch_mlp_bwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64
                    const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                    hipStream_t st);
 
+// mlp_mfma.hip — matrix-core implementation (3-term bf16 split, fp32-equivalent accuracy)
+int launch_mlp_fwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                        const float* w1, const float* w2, float* out, hipStream_t st);
+int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                        const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
+                        hipStream_t st);
+
 // warp.hip
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st);
 int launch_warp_bwd(const float* image, const float* grids, const float* dout, int nM, int H, int W,

@@ -10,6 +10,8 @@
 // products.  The weight-gradient outer products need a reduction over points;
 // they are staged through LDS ([point][hidden] image, padded) and accumulated
 // with lane = hidden unit.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace immoco {
@@ -173,9 +175,20 @@ __global__ __launch_bounds__(BWD_THREADS) void mlp_bwd_kernel(
   }
 }
 
+// IMMOCO_MLP_IMPL=valu selects the fp32 VALU kernels of this file (kept for A/B measurements);
+// the default is the matrix-core implementation in mlp_mfma.hip.
+static bool use_valu_impl() {
+  static const bool v = [] {
+    const char* e = getenv("IMMOCO_MLP_IMPL");
+    return e && strcmp(e, "valu") == 0;
+  }();
+  return v;
+}
+
 int launch_mlp_fwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                    const float* w1, const float* w2, float* out, hipStream_t st) {
   if (n == 0) return IMMOCO_OK;
+  if (!use_valu_impl()) return launch_mlp_fwd_mfma(cfg, in, ps, ls, n, w1, w2, out, st);
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   const unsigned grid = (unsigned)cdiv(n, 256);
 #define IMMOCO_FWD(H, A) mlp_fwd_kernel<H, A><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, out)
@@ -192,6 +205,7 @@ int launch_mlp_bwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64
                    const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                    hipStream_t st) {
   if (n == 0) return IMMOCO_OK;
+  if (!use_valu_impl()) return launch_mlp_bwd_mfma(cfg, in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st);
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   const int64_t n_batches = cdiv(n, 64);
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_batches, 2), 4096);
