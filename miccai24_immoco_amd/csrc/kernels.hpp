@@ -25,14 +25,14 @@ int launch_mlp_fwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64
                    const float* w1, const float* w2, float* out, hipStream_t st);
 int launch_mlp_bwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                    const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                   hipStream_t st);
+                   hipStream_t st, int64_t dout_plane = 0);  // dout_plane != 0: dout is planar [2][plane]
 
 // mlp_mfma.hip — matrix-core implementation (3-term bf16 split, fp32-equivalent accuracy)
 int launch_mlp_fwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                         const float* w1, const float* w2, float* out, hipStream_t st);
 int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                         const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                        hipStream_t st);
+                        hipStream_t st, int64_t dout_plane = 0);
 
 // warp.hip
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st);

@@ -263,9 +263,12 @@ __global__ __launch_bounds__(256) void ge_loss_kernel(const float2* __restrict__
         o.y += weight * gy;
         dimage[i] = o;
       } else {
+        // solver: PLANAR gradient image (re plane, im plane), see motion_warp_bwd_kernel
         const float s = ((r + c) & 1) ? -1.f : 1.f;
         const float2 a = adj0[i];
-        dimage[i] = make_float2(a.x * s + weight * gx, a.y * s + weight * gy);
+        float* pl = reinterpret_cast<float*>(dimage);
+        pl[i] = a.x * s + weight * gx;
+        pl[n + i] = a.y * s + weight * gy;
       }
     }
   }

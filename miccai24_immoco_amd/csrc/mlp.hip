@@ -77,7 +77,7 @@ template <int HID, int ACT>
 __global__ __launch_bounds__(BWD_THREADS) void mlp_bwd_kernel(
     const float* in /* may alias din */, int64_t ps, int64_t ls, int64_t n, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ dout, float* din,
-    float* __restrict__ dw1, float* __restrict__ dw2, int64_t n_batches) {
+    float* __restrict__ dw1, float* __restrict__ dw2, int64_t n_batches, int64_t dout_plane) {
   constexpr int NCH = HID / 64;
   __shared__ float lds[2][64 * A_LD + 32 * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -94,9 +94,14 @@ __global__ __launch_bounds__(BWD_THREADS) void mlp_bwd_kernel(
     float d0 = 0.f, d1 = 0.f;
     if (valid) {
       load_enc(in, p, ps, ls, e);
-      const float2 d = *reinterpret_cast<const float2*>(dout + p * 2);
-      d0 = d.x;
-      d1 = d.y;
+      if (dout_plane) {
+        d0 = dout[p];
+        d1 = dout[dout_plane + p];
+      } else {
+        const float2 d = *reinterpret_cast<const float2*>(dout + p * 2);
+        d0 = d.x;
+        d1 = d.y;
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 32; ++k) e[k] = 0.f;
@@ -203,14 +208,14 @@ int launch_mlp_fwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64
 
 int launch_mlp_bwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                    const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                   hipStream_t st) {
+                   hipStream_t st, int64_t dout_plane) {
   if (n == 0) return IMMOCO_OK;
-  if (!use_valu_impl()) return launch_mlp_bwd_mfma(cfg, in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st);
+  if (!use_valu_impl()) return launch_mlp_bwd_mfma(cfg, in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   const int64_t n_batches = cdiv(n, 64);
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_batches, 2), 4096);
 #define IMMOCO_BWD(H, A) \
-  mlp_bwd_kernel<H, A><<<grid, BWD_THREADS, 0, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_batches)
+  mlp_bwd_kernel<H, A><<<grid, BWD_THREADS, 0, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_batches, dout_plane)
   if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH) IMMOCO_BWD(64, IMMOCO_ACT_TANH);
   else if (cfg.n_hidden == 64) IMMOCO_BWD(64, IMMOCO_ACT_RELU);
   else if (cfg.activation == IMMOCO_ACT_TANH) IMMOCO_BWD(256, IMMOCO_ACT_TANH);
@@ -240,5 +245,5 @@ extern "C" int immoco_mlp_bwd(const immoco_mlp_cfg* cfg, const float* in, int64_
   if (rc) return rc;
   IMMOCO_REQUIRE(n >= 0 && (n == 0 || (in && w1 && w2 && dout && din && dw1 && dw2)), "mlp_bwd: NULL buffer");
   return launch_mlp_bwd(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, dout, din, dw1, dw2,
-                        as_stream(stream));
+                        as_stream(stream), 0);
 }

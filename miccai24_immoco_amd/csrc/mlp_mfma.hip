@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
                                                            const float* __restrict__ w2,
                                                            const float* __restrict__ dout, float* din,
                                                            float* __restrict__ dw1, float* __restrict__ dw2,
-                                                           int64_t n_tiles) {
+                                                           int64_t n_tiles, int64_t dout_plane) {
   constexpr int NJT = HID / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* aw = reinterpret_cast<u32x4*>(smem);                  // W1 fragments        [NJT*2][3][64]
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
       eb[ks] = split3(x);
     }
     float2 d = make_float2(0.f, 0.f);
-    if (valid) d = *reinterpret_cast<const float2*>(dout + p * 2);
+    if (valid) d = dout_plane ? make_float2(dout[p], dout[dout_plane + p]) : *reinterpret_cast<const float2*>(dout + p * 2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier readers of dos (previous tile) are done
     if (h == 0) *reinterpret_cast<float2*>(dos + 2 * r) = d;
     // enc^T fragments (rows = feature r, K = points in accumulator order)
@@ -372,7 +372,7 @@ int launch_mlp_fwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
 
 template <int HID, int ACT>
 static int launch_bwd_t(const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1, const float* w2,
-                        const float* dout, float* din, float* dw1, float* dw2, hipStream_t st) {
+                        const float* dout, float* din, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane) {
   const int64_t n_tiles = cdiv(n, 32);
   // HID = 256 keeps 8 accumulator tiles per wave: one wave per SIMD (512-register budget)
   const int blocks_per_cu = HID == 64 ? 2 : 1;
@@ -384,22 +384,22 @@ static int launch_bwd_t(const float* in, int64_t ps, int64_t ls, int64_t n, cons
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     attr_set = true;
   }
-  mlp_bwd_mfma_kernel<HID, ACT><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles);
+  mlp_bwd_mfma_kernel<HID, ACT><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles, dout_plane);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
 
 int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                         const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                        hipStream_t st) {
+                        hipStream_t st, int64_t dout_plane) {
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH)
-    return launch_bwd_t<64, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st);
-  if (cfg.n_hidden == 64) return launch_bwd_t<64, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st);
+    return launch_bwd_t<64, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
+  if (cfg.n_hidden == 64) return launch_bwd_t<64, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
   if (cfg.activation == IMMOCO_ACT_TANH)
-    return launch_bwd_t<256, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st);
-  return launch_bwd_t<256, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st);
+    return launch_bwd_t<256, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
+  return launch_bwd_t<256, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
 }
 
 }  // namespace immoco

@@ -146,7 +146,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   }
   st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
                   return launch_mlp_bwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
-                                        g_w1i, g_w2i, q);
+                                        g_w1i, g_w2i, q, /*planar dimage*/ P);
                 }});
   st.push_back({"image_encode_bwd", [=](hipStream_t q) {
                   if (s->plan_img) return launch_csr_bwd(s->plan_img, s->enc_img, g_tabi, 0, 1, q);

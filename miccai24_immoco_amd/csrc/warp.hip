@@ -134,22 +134,73 @@ __global__ __launch_bounds__(256) void motion_warp_fwd_kernel(const float2* __re
   slots[i] = make_float2(v.x * s, v.y * s);
 }
 
+// Backward of the fused warp.  The image gradient is accumulated with float atomics into a PLANAR
+// buffer dpl[0..P) = d/dRe, dpl[P..2P) = d/dIm, so that one atomic wave-instruction covers 256
+// contiguous bytes (the fast shape; interleaved complex halves that).  Neighbouring lanes
+// (neighbouring pixels of one row) nearly always sample neighbouring source columns: the right tap
+// column of lane l is the left tap column of lane l+1.  Lanes exchange that column through
+// shuffles and each source pixel is added once per pair, which halves the atomics again
+// (rocprof before: 5.5 M atomic requests, 0.29 ms per iteration).
 __global__ __launch_bounds__(256) void motion_warp_bwd_kernel(const float2* __restrict__ img,
                                                               const float2* __restrict__ t_in,
                                                               const float* __restrict__ xs,
                                                               const float* __restrict__ ys,
                                                               const float2* __restrict__ adj, int64_t n,
-                                                              int H, int W, float* __restrict__ dimg,
+                                                              int H, int W, float* __restrict__ dpl,
                                                               float2* __restrict__ d_o) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int c = (int)(i % W), r = (int)((i / W) % H);
-  const float2 t = t_in[i];
-  const float s = ((r + c) & 1) ? -1.f : 1.f;
-  const float2 a = adj[i];
-  const float2 go = make_float2(a.x * s, a.y * s);
-  const float2 dg = sample_bwd(img, dimg, make_taps(t.x + xs[c], t.y + ys[r], H, W), go, H, W);
-  d_o[i] = make_float2(dg.x * (1.f - t.x * t.x), dg.y * (1.f - t.y * t.y));
+  const int lane = threadIdx.x & 63;
+  const bool active = i < n;
+  const int64_t P = (int64_t)H * W;
+  int x0 = -1000, y0 = -1000;
+  float2 L0 = make_float2(0.f, 0.f), L1 = L0, R0 = L0, R1 = L0;
+  if (active) {
+    const int c = (int)(i % W), r = (int)((i / W) % H);
+    const float2 t = t_in[i];
+    const float s = ((r + c) & 1) ? -1.f : 1.f;
+    const float2 a = adj[i];
+    const float2 go = make_float2(a.x * s, a.y * s);
+    const Taps tp = make_taps(t.x + xs[c], t.y + ys[r], H, W);
+    const float2 dg = sample_bwd(img, nullptr, tp, go, H, W);
+    d_o[i] = make_float2(dg.x * (1.f - t.x * t.x), dg.y * (1.f - t.y * t.y));
+    x0 = tp.x0;
+    y0 = tp.y0;
+    L0 = make_float2(tp.nw * go.x, tp.nw * go.y);
+    R0 = make_float2(tp.ne * go.x, tp.ne * go.y);
+    L1 = make_float2(tp.sw * go.x, tp.sw * go.y);
+    R1 = make_float2(tp.se * go.x, tp.se * go.y);
+  }
+  const int px0 = __shfl_up(x0, 1, 64), py0 = __shfl_up(y0, 1, 64);
+  const int nx0 = __shfl_down(x0, 1, 64), ny0 = __shfl_down(y0, 1, 64);
+  const float pr0x = __shfl_up(R0.x, 1, 64), pr0y = __shfl_up(R0.y, 1, 64);
+  const float pr1x = __shfl_up(R1.x, 1, 64), pr1y = __shfl_up(R1.y, 1, 64);
+  const bool take_prev = lane > 0 && px0 + 1 == x0 && py0 == y0;
+  const bool next_takes = lane < 63 && nx0 == x0 + 1 && ny0 == y0;
+  if (take_prev) {
+    L0.x += pr0x;
+    L0.y += pr0y;
+    L1.x += pr1x;
+    L1.y += pr1y;
+  }
+  if (!active) return;
+  if (inb(y0, x0, H, W)) {
+    unsafeAtomicAdd(dpl + (size_t)y0 * W + x0, L0.x);
+    unsafeAtomicAdd(dpl + P + (size_t)y0 * W + x0, L0.y);
+  }
+  if (inb(y0 + 1, x0, H, W)) {
+    unsafeAtomicAdd(dpl + (size_t)(y0 + 1) * W + x0, L1.x);
+    unsafeAtomicAdd(dpl + P + (size_t)(y0 + 1) * W + x0, L1.y);
+  }
+  if (!next_takes) {
+    if (inb(y0, x0 + 1, H, W)) {
+      unsafeAtomicAdd(dpl + (size_t)y0 * W + x0 + 1, R0.x);
+      unsafeAtomicAdd(dpl + P + (size_t)y0 * W + x0 + 1, R0.y);
+    }
+    if (inb(y0 + 1, x0 + 1, H, W)) {
+      unsafeAtomicAdd(dpl + (size_t)(y0 + 1) * W + x0 + 1, R1.x);
+      unsafeAtomicAdd(dpl + P + (size_t)(y0 + 1) * W + x0 + 1, R1.y);
+    }
+  }
 }
 
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st) {
