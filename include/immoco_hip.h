@@ -177,7 +177,9 @@ typedef struct immoco_solver_cfg {
                              kept for A/B measurements); 0: transposed-index gather (default) */
   int32_t grad_parts;     /* point-range parts of the motion grid's transposed index (1, 2, 4 or 8;
                              0 = default 4): each XCD keeps a 8/parts MB slice of dL/denc in its L2 */
-  int32_t reserved[5];
+  int32_t serial_chains;  /* 1: run the image-INR and motion-INR kernel chains one after the other
+                             (default 0: two concurrent branches of the graph) */
+  int32_t reserved[4];
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;

@@ -18,9 +18,14 @@ namespace immoco {
 
 __global__ void tick_kernel(int32_t* it) { *it += 1; }
 
+// branch 0: serial section on the main stream; branch 1 / 2: two independent chains that run
+// concurrently (main / side stream) between a fork and the next serial step (join).  The image-INR
+// kernels are small grids (102 400 points) that cannot fill 256 CUs on their own; they overlap with
+// the motion-INR chain.
 struct Step {
   const char* name;
   std::function<int(hipStream_t)> run;
+  int branch = 0;
 };
 
 }  // namespace immoco
@@ -45,8 +50,9 @@ struct immoco_solver {
   int32_t* iter_dev = nullptr;
   int32_t sched_cap = 0;
   int64_t bytes = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, side = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  hipEvent_t ev_fj[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // graph cache: valid while the captured pointers stay the same
   hipGraphExec_t gexec = nullptr;
   std::vector<const void*> gkey;
@@ -103,18 +109,18 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   std::vector<Step> st;
   st.push_back({"image_encode_fwd", [=](hipStream_t q) {
                   return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, 2, 2 * P, q);
-                }});
+                }, 2});
   st.push_back({"image_mlp_fwd", [=](hipStream_t q) {
                   return launch_mlp_fwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
-                }});
-  st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }});
+                }, 2});
+  st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }, 2});
   if (nM > 0) {
     st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
                     return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
-                  }});
+                  }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
-                  }});
+                  }, 1});
     st.push_back({"motion_warp_fwd", [=](hipStream_t q) {
                     return launch_motion_warp_fwd(s->image, s->o_mot, s->xs, s->ys, nM, H, W, s->t_mot, slot1, q);
                   }});
@@ -138,31 +144,31 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
                     return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
                                           s->enc_mot, g_w1m, g_w2m, q);
-                  }});
+                  }, 1});
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
                     if (s->plan_mot) return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q);
                     return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
-                  }});
+                  }, 1});
   }
   st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
                   return launch_mlp_bwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
                                         g_w1i, g_w2i, q, /*planar dimage*/ P);
-                }});
+                }, 2});
   st.push_back({"image_encode_bwd", [=](hipStream_t q) {
                   if (s->plan_img) return launch_csr_bwd(s->plan_img, s->enc_img, g_tabi, 0, 1, q);
                   return launch_hashgrid_bwd(s->lv_img, nullptr, &li, P, s->enc_img, 2, 2 * P, g_tabi, q);
-                }});
+                }, 2});
   // optimizer param-group order of the reference: motion first, then image (immoco.py:149-154)
   if (nM > 0)
     st.push_back({"adam_motion", [=](hipStream_t q) {
                     return launch_adam_sched(b.p_mot, s->grad_mot, s->plan_mot ? s->mot_parts : 1, s->mot_gstride,
                                              b.a_mot, b.a_mot + s->n_params_mot, s->n_params_mot, s->sched,
                                              s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
-                  }});
+                  }, 1});
   st.push_back({"adam_image", [=](hipStream_t q) {
                   return launch_adam_sched(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
                                            s->n_params_img, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
-                }});
+                }, 2});
   st.push_back({"tick", [=](hipStream_t q) {
                   tick_kernel<<<1, 1, 0, q>>>(s->iter_dev);
                   IMMOCO_LAUNCH_CHECK();
@@ -178,6 +184,9 @@ int run_steps(const std::vector<Step>& steps, hipStream_t q) {
   }
   return IMMOCO_OK;
 }
+
+// fork/join execution of the branch annotations (works eagerly and under stream capture)
+int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q);
 
 int ensure_sched(immoco_solver* s, int32_t iters) {
   if (iters <= s->sched_cap) return IMMOCO_OK;
@@ -206,6 +215,33 @@ int leave(immoco_solver* s, hipStream_t caller) {
   return IMMOCO_OK;
 }
 
+}  // namespace
+
+namespace {
+int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q) {
+  bool forked = false;
+  int ev = 0;
+  for (const Step& st : steps) {
+    if (st.branch != 0 && !forked) {  // fork: the side stream starts after everything issued so far
+      IMMOCO_CHECK_HIP(hipEventRecord(s->ev_fj[ev], q));
+      IMMOCO_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fj[ev], 0));
+      ev = (ev + 1) % 8;
+      forked = true;
+    } else if (st.branch == 0 && forked) {  // join
+      IMMOCO_CHECK_HIP(hipEventRecord(s->ev_fj[ev], s->side));
+      IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, s->ev_fj[ev], 0));
+      ev = (ev + 1) % 8;
+      forked = false;
+    }
+    int rc = st.run(st.branch == 2 ? s->side : q);
+    if (rc) return rc;
+  }
+  if (forked) {
+    IMMOCO_CHECK_HIP(hipEventRecord(s->ev_fj[ev], s->side));
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, s->ev_fj[ev], 0));
+  }
+  return IMMOCO_OK;
+}
 }  // namespace
 
 extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_t* out) {
@@ -255,6 +291,8 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   A(ms, cfg->nM > 0 ? cfg->nM : 1)
 #undef A
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
+  for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ev_fj[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(s->grad_img, 0, (size_t)s->n_params_img * 4);
@@ -286,6 +324,9 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   if (s->iter_dev) hipFree(s->iter_dev);
   if (s->ev_in) hipEventDestroy(s->ev_in);
   if (s->ev_out) hipEventDestroy(s->ev_out);
+  for (hipEvent_t ev : s->ev_fj)
+    if (ev) hipEventDestroy(ev);
+  if (s->side) hipStreamDestroy(s->side);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
   return IMMOCO_OK;
@@ -374,7 +415,7 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
       hipGraph_t graph = nullptr;
       hipError_t e = hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
-        rc = run_steps(steps, q);
+        rc = s->cfg.serial_chains ? run_steps(steps, q) : run_steps_forked(s, steps, q);
         hipError_t e2 = hipStreamEndCapture(q, &graph);
         if (rc == IMMOCO_OK && e2 == hipSuccess && graph) {
           if (hipGraphInstantiate(&s->gexec, graph, nullptr, nullptr, 0) != hipSuccess) s->gexec = nullptr;
@@ -389,7 +430,7 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   for (int j = 0; j < iters; ++j) {
     if (s->graph_active) {
       IMMOCO_CHECK_HIP(hipGraphLaunch(s->gexec, q));
-    } else if ((rc = run_steps(steps, q))) {
+    } else if ((rc = s->cfg.serial_chains ? run_steps(steps, q) : run_steps_forked(s, steps, q))) {
       return rc;
     }
   }
