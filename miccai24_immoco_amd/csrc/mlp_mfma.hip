@@ -110,16 +110,19 @@ __device__ __forceinline__ Frag3 lds_load_frag(const u32x4* base, int f, int lan
   return v;
 }
 
-// fragment of the point tile: element i = in[point p0 + r][feature 16*ks + 8h + i] (0 beyond n)
-__device__ __forceinline__ void load_enc_frag(const float* in, int64_t ps, int64_t ls, int64_t p, bool valid, int ks,
+// fragment of the point tile: element i = in[point p][feature 16*ks + 8h + i] (0 beyond n).
+// The loads are UNCONDITIONAL on a clamped address and masked afterwards: a load under a divergent
+// `if` gets its own basic block and its own s_waitcnt, which serialises the whole tile prologue.
+__device__ __forceinline__ void load_enc_frag(const float* in, int64_t ps, int64_t ls, int64_t p, int64_t n, int ks,
                                               int h, float (&x)[8]) {
+  const int64_t pc = p < n ? p : n - 1;
+  const float m = p < n ? 1.f : 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int level = 8 * ks + 4 * h + q;
-    float2 v = make_float2(0.f, 0.f);
-    if (valid) v = *reinterpret_cast<const float2*>(in + p * ps + (int64_t)level * ls);
-    x[2 * q] = v.x;
-    x[2 * q + 1] = v.y;
+    const float2 v = *reinterpret_cast<const float2*>(in + pc * ps + (int64_t)level * ls);
+    x[2 * q] = v.x * m;
+    x[2 * q + 1] = v.y * m;
   }
 }
 
@@ -148,15 +151,22 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restri
   __syncthreads();
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
+  // software pipeline: the next tile's raw operands are in flight while this one is computed
+  float nx[2][8];
+  if (wave_id < n_tiles) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) load_enc_frag(in, ps, ls, wave_id * 32 + r, n, ks, h, nx[ks]);
+  }
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
     const int64_t p = t * 32 + r;
     const bool valid = p < n;
     Frag3 eb[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      float x[8];
-      load_enc_frag(in, ps, ls, p, valid, ks, h, x);
-      eb[ks] = split3(x);
+    for (int ks = 0; ks < 2; ++ks) eb[ks] = split3(nx[ks]);
+    if (t + n_waves < n_tiles) {
+      const int64_t pn = (t + n_waves) * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) load_enc_frag(in, ps, ls, pn, n, ks, h, nx[ks]);
     }
     float o0 = 0.f, o1 = 0.f;
 #pragma unroll 2
@@ -223,6 +233,33 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
   }
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
+  // software pipeline: raw operands of the NEXT tile are loaded while the current one is computed
+  float nx_e[2][8], nx_t[2][8];
+  float2 nx_d = make_float2(0.f, 0.f);
+  auto load_raw = [&](int64_t tt) {
+    const int64_t q0 = tt * 32, q = q0 + r;
+    const int64_t qc = q < n ? q : n - 1;
+    const float mq = q < n ? 1.f : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) load_enc_frag(in, ps, ls, q, n, ks, h, nx_e[ks]);
+    if (dout_plane) {  // wave-uniform
+      nx_d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
+    } else {
+      const float2 dv = *reinterpret_cast<const float2*>(dout + qc * 2);
+      nx_d = make_float2(dv.x * mq, dv.y * mq);
+    }
+    // enc^T fragments (rows = feature r, K = points in accumulator order)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t qq = q0 + 16 * s2 + 8 * (i >> 2) + 4 * h + (i & 3);
+        const int64_t qqc = qq < n ? qq : n - 1;
+        const float v = in[qqc * ps + (int64_t)(r >> 1) * ls + (r & 1)];
+        nx_t[s2][i] = qq < n ? v : 0.f;
+      }
+  };
+  if (wave_id < n_tiles) load_raw(wave_id);
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
     const int64_t p0 = t * 32, p = p0 + r;
     const bool valid = p < n;
@@ -230,25 +267,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
     Frag3 eb[2], et[2], dt[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      float x[8];
-      load_enc_frag(in, ps, ls, p, valid, ks, h, x);
-      eb[ks] = split3(x);
+      eb[ks] = split3(nx_e[ks]);
+      et[ks] = split3(nx_t[ks]);
     }
-    float2 d = make_float2(0.f, 0.f);
-    if (valid) d = dout_plane ? make_float2(dout[p], dout[dout_plane + p]) : *reinterpret_cast<const float2*>(dout + p * 2);
+    const float2 d = nx_d;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier readers of dos (previous tile) are done
     if (h == 0) *reinterpret_cast<float2*>(dos + 2 * r) = d;
-    // enc^T fragments (rows = feature r, K = points in accumulator order)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float x[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t q = p0 + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3);
-        x[i] = q < n ? in[q * ps + (int64_t)(r >> 1) * ls + (r & 1)] : 0.f;
-      }
-      et[s] = split3(x);
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // dos visible to the whole wave
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -260,6 +284,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
       }
       dt[s] = split3(x);
     }
+    if (t + n_waves < n_tiles) load_raw(t + n_waves);
     f32x16 denc = {0.f};
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {

@@ -23,7 +23,7 @@ def gather_images(local: torch.Tensor, n_total: int, group=None, dst: Optional[i
     """local [n_local, H, W] complex64 of this rank's block -> [n_total, H, W] on every rank
     (dst=None, all_gather) or on rank `dst` only (gather).  Ragged blocks are padded to the
     largest block for the collective and trimmed afterwards."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     H, W = local.shape[-2:]
