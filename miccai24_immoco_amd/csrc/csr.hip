@@ -230,11 +230,16 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(Levels lv, AxisPtrs<D> ax,
       if (v != 0.f) unsafeAtomicAdd(out + i, v);
     }
   } else {
-    // exclusive owner of these (part, slot) pairs: no atomics; a plain store when the caller
-    // guarantees a zeroed buffer (solver: Adam's fused zero_grad), else read-modify-write
-    for (int i = tid; i < 2 * (int)it.ns; i += 256) {
-      const float v = acc[i];
-      if (v != 0.f) out[i] = zeroed ? v : out[i] + v;
+    // exclusive owner of these (part, slot) pairs: no atomics.  Solver mode (`zeroed`): the tile is
+    // OVERWRITTEN every iteration (zeros included), so nobody has to clear it (Adam's fused
+    // zero_grad skips these ranges: 16 B/param less HBM traffic); op-level mode accumulates.
+    if (zeroed) {
+      for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = acc[i];
+    } else {
+      for (int i = tid; i < 2 * (int)it.ns; i += 256) {
+        const float v = acc[i];
+        if (v != 0.f) out[i] += v;
+      }
     }
   }
 }
@@ -257,6 +262,7 @@ struct CsrPlan {
   uint32_t n_items = 0;
   uint64_t n_entries = 0;
   int64_t bytes = 0;
+  uint32_t shared_slot_end = 0;  // slots < this may belong to "shared" (atomic-flush) items
 };
 
 void csr_plan_free(CsrPlan* p) {
@@ -320,6 +326,7 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
           for (uint32_t e = e0; e < e_end; e += ENTRIES_PER_ITEM)
             per_part[q].push_back({e, std::min<uint32_t>(e + ENTRIES_PER_ITEM, e_end), lv.offset[l] + s, 1u,
                                    (uint32_t)l, (uint32_t)q | (1u << 16)});
+          pl->shared_slot_end = std::max(pl->shared_slot_end, lv.offset[l] + s + 1);
           s = s + 1;
         } else {
           if (h_offs[cb + s1] > e0)
@@ -387,6 +394,7 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
 
 int64_t csr_plan_bytes(const CsrPlan* p) { return p ? p->bytes : 0; }
 int csr_plan_parts(const CsrPlan* p) { return p ? p->n_parts : 1; }
+uint32_t csr_plan_shared_slot_end(const CsrPlan* p) { return p ? p->shared_slot_end : 0; }
 
 // dtable: n_parts partial tables, `part_stride` floats apart.  zeroed != 0: the caller guarantees
 // that the buffers hold zeros (plain stores); otherwise the results are accumulated.

@@ -70,9 +70,10 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float s
                 float beta1, float beta2, float eps, hipStream_t st);
 // device-scheduled variant: scalars read from sched[2*it], it = *iter_dev; g zeroed after use
 // g: n_gparts partial gradient buffers, g_stride floats apart; their sum is the gradient
+// gradients with index >= zero_limit are NOT cleared (their producer overwrites them every iteration)
 int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n,
-                      const float* sched, const int32_t* iter_dev, float beta1, float beta2, float eps,
-                      hipStream_t st);
+                      int64_t zero_limit, const float* sched, const int32_t* iter_dev, float beta1, float beta2,
+                      float eps, hipStream_t st);
 
 // csr.hip — atomic-free hash-grid backward for fixed lattices
 struct CsrPlan;
@@ -81,6 +82,7 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
 void csr_plan_free(CsrPlan* p);
 int64_t csr_plan_bytes(const CsrPlan* p);
 int csr_plan_parts(const CsrPlan* p);
+uint32_t csr_plan_shared_slot_end(const CsrPlan* p);  // table slots below this need zeroing by the consumer
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,
                    int zeroed, hipStream_t st);
 

@@ -20,7 +20,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 template <bool SCHED>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, int n_gparts,
                                                    int64_t g_stride, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n,
+                                                   float* __restrict__ v, int64_t n, int64_t zero_limit,
                                                    float step_size, float bc2_sqrt,
                                                    const float* __restrict__ sched,
                                                    const int32_t* __restrict__ iter_dev, float b1, float b2,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
-    if (SCHED)  // fused zero_grad
+    if (SCHED && 4 * i < zero_limit)  // fused zero_grad (skipped where the producer overwrites)
       for (int q = 0; q < n_gparts; ++q) reinterpret_cast<float4*>(g + q * g_stride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // tail
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float gt = g[t];
     for (int q = 1; q < n_gparts; ++q) gt += g[q * g_stride + t];
     adam_one(p[t], gt, m[t], v[t], step_size, bc2_sqrt, b1, b2, eps);
-    if (SCHED)
+    if (SCHED && t < zero_limit)
       for (int q = 0; q < n_gparts; ++q) g[q * g_stride + t] = 0.f;
   }
 }
@@ -72,20 +72,20 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float s
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
-  adam_kernel<false><<<adam_grid(n), 256, 0, st>>>(p, const_cast<float*>(g), 1, 0, m, v, n, step_size, bc2_sqrt,
+  adam_kernel<false><<<adam_grid(n), 256, 0, st>>>(p, const_cast<float*>(g), 1, 0, m, v, n, n, step_size, bc2_sqrt,
                                                    nullptr, nullptr, beta1, beta2, eps);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
 
 int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n,
-                      const float* sched, const int32_t* iter_dev, float beta1, float beta2, float eps,
-                      hipStream_t st) {
+                      int64_t zero_limit, const float* sched, const int32_t* iter_dev, float beta1, float beta2,
+                      float eps, hipStream_t st) {
   IMMOCO_REQUIRE(n_gparts >= 1 && (g_stride % 4) == 0, "adam: partial gradient stride must be a multiple of 4");
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
-  adam_kernel<true><<<adam_grid(n), 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n, 0.f, 1.f, sched, iter_dev, beta1,
+  adam_kernel<true><<<adam_grid(n), 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n, zero_limit, 0.f, 1.f, sched, iter_dev, beta1,
                                                   beta2, eps);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
