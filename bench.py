@@ -125,9 +125,9 @@ def main():
     slices = []
     for j in range(Wm + K):
         gidx = rank * (Wm + K) + j
-        s = synth.make_slice(H, W, N_MOVEMENTS, gidx)
-        masks = pkg.extract_movement_groups(s["lines"].to(dev), make_list=True)
-        slices.append({"kspace": s["kspace"].to(dev), "masks": masks, "gt": s["gt"]})
+        s = synth.make_slice(H, W, N_MOVEMENTS, gidx, device=dev)     # HIP motion simulator
+        masks = pkg.extract_movement_groups(s["lines"], make_list=True)
+        slices.append({"kspace": s["kspace"], "masks": masks, "gt": s["gt"].cpu()})
     nM = int(slices[0]["masks"].shape[0])
     get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts)      # plans + workspace (one-off, like FFT plan creation)
 

@@ -122,6 +122,17 @@ int immoco_warp_fwd(const float* image /*[H,W] c64*/, const float* grids /*[nM,H
 int immoco_warp_bwd(const float* image, const float* grids, const float* dout, int32_t nM,
                     int32_t H, int32_t W, float* dimage, float* dgrids, void* stream);
 
+/* ---- motion simulator (src/utils/motion_utils.py:121-202), the input generator of the path ---
+ * F.affine_grid(theta, align_corners=True) + F.grid_sample(bilinear, border, align_corners=False)
+ * of one complex image for n rigid movements.  theta [n][2][3] fp32 (device), xs[W] / ys[H] the
+ * linspace(-1,1,.) base lattices; out [n,H,W] c64. */
+int immoco_affine_warp_border(const float* image, const float* theta, const float* xs, const float* ys,
+                              int32_t n, int32_t H, int32_t W, float* out, void* stream);
+/* kout[..., w0[m]:w1[m]] = kall[m][..., w0[m]:w1[m]] for m = 0..n-1 in order, kout = k0 elsewhere;
+ * mask [H,W] int64 (may be NULL) = 1 on replaced columns (motion_utils.py:191-196). */
+int immoco_band_replace(const float* k0, const float* kall, const int32_t* w0, const int32_t* w1,
+                        int32_t n, int32_t H, int32_t W, float* kout, int64_t* mask, void* stream);
+
 /* ---- centred FFTs (src/utils/data_utils.py:29-34) over the last two dims.
  * mode 0: FFT  = fftshift(fftn(ifftshift(x)))   unnormalised
  * mode 1: IFFT = ifftshift(ifftn(fftshift(x)))  1/(HW)

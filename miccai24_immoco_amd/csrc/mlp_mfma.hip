@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // backward
 template <int HID, int ACT>
-__global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* may alias din */, int64_t ps, int64_t ls,
+__global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(const float* in /* may alias din */, int64_t ps, int64_t ls,
                                                            int64_t n, const float* __restrict__ w1,
                                                            const float* __restrict__ w2,
                                                            const float* __restrict__ dout, float* din,
@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
   u32x4* awt = aw + NJT * 2 * 3 * 64;                          // W1^T fragments      [NJT*2][3][64]
   float* w2s = reinterpret_cast<float*>(awt + NJT * 2 * 3 * 64);  // [2][HID]
   float* dos_all = w2s + 2 * HID;                              // per wave [32][2] dout staging
-  float* tr_all = dos_all + 4 * 64;                            // per wave [32][33] flush transpose
+  float* tr_all = dos_all + 4 * 64;                            // per wave [32][36] transpose tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   float* dos = dos_all + wave * 64;
-  float* tr = tr_all + wave * 32 * 33;
+  float* tr = tr_all + wave * 32 * 36;
   for (int f = wave; f < NJT * 2; f += 4) {
     const int jt = f >> 1, s = f & 1;
     float x[8];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
       f32x16 pre = {0.f};
       mfma6(pre, a0, eb[0]);
       mfma6(pre, a1, eb[1]);
-      float dp[16];
+      float dp[16], hv1[16];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const float4 wa = *reinterpret_cast<const float4*>(w2s + jt * 32 + 8 * a + 4 * h);
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
         for (int b = 0; b < 4; ++b) {
           const float pv = pre[4 * a + b];
           const float hv = act_f<ACT>(pv);
+          hv1[4 * a + b] = hv;
           dp[4 * a + b] = fmaf(was[b], d.x, wbs[b] * d.y) * act_d<ACT>(pv, hv);
         }
       }
@@ -313,19 +314,30 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
         for (int i = 0; i < 8; ++i) x[i] = dp[8 * s + i];
         mfma6(denc, lds_load_frag(awt, jt * 2 + s, lane), split3(x));
       }
-      // ---- layout 2: rows = point, col = hidden
-      f32x16 prt = {0.f};
-      mfma6(prt, eb[0], a0);
-      mfma6(prt, eb[1], a1);
+      // ---- layout 2: rows = point, col = hidden.  h' is the transpose of h: it goes through a
+      // per-wave LDS tile (16 ds_write_b32 + 4 ds_read_b128, both conflict-free with a 36-float
+      // row) instead of being recomputed (12 MFMAs + 16 activations; tanh alone was 37 % of the
+      // kernel's VALU instructions).  act' depends on h only (relu: h > 0; tanh: 1 - h^2).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous readers of the tile are done
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tr[drow(g, h) * 36 + r] = hv1[g];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const float w20 = w2s[jt * 32 + r], w21 = w2s[HID + jt * 32 + r];
       float hp[16];
 #pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float4 q4 = *reinterpret_cast<const float4*>(tr + r * 36 + 8 * a + 4 * h);
+        hp[4 * a] = q4.x;
+        hp[4 * a + 1] = q4.y;
+        hp[4 * a + 2] = q4.z;
+        hp[4 * a + 3] = q4.w;
+      }
+#pragma unroll
       for (int g = 0; g < 16; ++g) {
         const float2 dq = *reinterpret_cast<const float2*>(dos + 2 * drow(g, h));
-        const float pv = prt[g];
-        const float hv = act_f<ACT>(pv);
-        hp[g] = hv;
-        dp[g] = fmaf(w20, dq.x, w21 * dq.y) * act_d<ACT>(pv, hv);
+        const float hv = hp[g];
+        const float dact = ACT == IMMOCO_ACT_RELU ? (hv > 0.f ? 1.f : 0.f) : 1.f - hv * hv;
+        dp[g] = fmaf(w20, dq.x, w21 * dq.y) * dact;
       }
       f32x16 tmp = {0.f};
 #pragma unroll
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma_kernel(const float* in /* ma
 
 static size_t fwd_smem(int hid) { return (size_t)(hid / 32) * 2 * 3 * 64 * 16 + (size_t)2 * hid * 4; }
 static size_t bwd_smem(int hid) {
-  return (size_t)(hid / 32) * 2 * 3 * 64 * 16 * 2 + (size_t)2 * hid * 4 + 4 * 64 * 4 + (size_t)4 * 32 * 33 * 4;
+  return (size_t)(hid / 32) * 2 * 3 * 64 * 16 * 2 + (size_t)2 * hid * 4 + 4 * 64 * 4 + (size_t)4 * 32 * 36 * 4;
 }
 
 int launch_mlp_fwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,

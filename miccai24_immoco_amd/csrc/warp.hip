@@ -310,6 +310,52 @@ __global__ __launch_bounds__(256) void motion_warp_bwd_tiled_kernel(const float2
   }
 }
 
+// ---- motion simulator pieces (reference src/utils/motion_utils.py:165-195) ---------------------
+// affine_grid(theta, align_corners=True) followed by grid_sample(bilinear, padding_mode="border",
+// align_corners=False) of one complex image for n rigid movements.  ATen semantics: the
+// unnormalised coordinate is clipped to [0, size-1] before the bilinear taps are taken.
+__global__ __launch_bounds__(256) void affine_warp_border_kernel(const float2* __restrict__ img,
+                                                                 const float* __restrict__ theta /*[n][2][3]*/,
+                                                                 const float* __restrict__ xs,
+                                                                 const float* __restrict__ ys, int64_t n_tot, int H,
+                                                                 int W, float2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_tot) return;
+  const int c = (int)(i % W), r = (int)((i / W) % H);
+  const int m = (int)(i / ((int64_t)W * H));
+  const float* t = theta + 6 * m;
+  const float x = xs[c], y = ys[r];
+  const float gx = x * t[0] + y * t[1] + t[2], gy = x * t[3] + y * t[4] + t[5];
+  float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx1 = ix - fx, tx0 = (fx + 1.f) - ix, ty1 = iy - fy, ty0 = (fy + 1.f) - iy;
+  const float2 a = ld_or_zero(img, y0, x0, H, W), b = ld_or_zero(img, y0, x0 + 1, H, W);
+  const float2 cc = ld_or_zero(img, y0 + 1, x0, H, W), d = ld_or_zero(img, y0 + 1, x0 + 1, H, W);
+  const float nw = tx0 * ty0, ne = tx1 * ty0, sw = tx0 * ty1, se = tx1 * ty1;
+  out[i] = make_float2(a.x * nw + b.x * ne + cc.x * sw + d.x * se, a.y * nw + b.y * ne + cc.y * sw + d.y * se);
+}
+
+// ksp[..., w0:w1] = ksp_m[m][..., w0:w1] applied for m = 0..n-1 in order (a later movement
+// overwrites an earlier one where bands overlap), mask[:, w0:w1] = 1   (motion_utils.py:191-196)
+__global__ __launch_bounds__(256) void band_replace_kernel(const float2* __restrict__ k0,
+                                                           const float2* __restrict__ kall,
+                                                           const int32_t* __restrict__ w0,
+                                                           const int32_t* __restrict__ w1, int n, int H, int W,
+                                                           float2* __restrict__ kout, int64_t* __restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t P = (int64_t)H * W;
+  if (i >= P) return;
+  const int c = (int)(i % W);
+  int sel = -1;
+  for (int m = 0; m < n; ++m)
+    if (c >= w0[m] && c < w1[m]) sel = m;
+  kout[i] = sel >= 0 ? kall[(int64_t)sel * P + i] : k0[i];
+  if (mask) mask[i] = sel >= 0 ? 1 : 0;
+}
+
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st) {
   const int64_t n = (int64_t)nM * H * W;
   if (n == 0) return IMMOCO_OK;
@@ -384,4 +430,26 @@ extern "C" int immoco_warp_bwd(const float* image, const float* grids, const flo
   IMMOCO_REQUIRE(nM >= 0 && H > 0 && W > 0, "warp_bwd: bad shape nM=%d H=%d W=%d", nM, H, W);
   IMMOCO_REQUIRE(nM == 0 || (image && grids && dout && dgrids), "warp_bwd: NULL buffer");
   return launch_warp_bwd(image, grids, dout, nM, H, W, dimage, dgrids, as_stream(stream));
+}
+
+extern "C" int immoco_affine_warp_border(const float* image, const float* theta, const float* xs, const float* ys,
+                                         int32_t n, int32_t H, int32_t W, float* out, void* stream) {
+  IMMOCO_REQUIRE(n >= 0 && H > 0 && W > 0, "affine_warp_border: bad shape n=%d H=%d W=%d", n, H, W);
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(image && theta && xs && ys && out, "affine_warp_border: NULL buffer");
+  const int64_t tot = (int64_t)n * H * W;
+  affine_warp_border_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, as_stream(stream)>>>(
+      (const float2*)image, theta, xs, ys, tot, H, W, (float2*)out);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+extern "C" int immoco_band_replace(const float* k0, const float* kall, const int32_t* w0, const int32_t* w1,
+                                   int32_t n, int32_t H, int32_t W, float* kout, int64_t* mask, void* stream) {
+  IMMOCO_REQUIRE(n >= 0 && H > 0 && W > 0 && k0 && kout, "band_replace: bad argument");
+  IMMOCO_REQUIRE(n == 0 || (kall && w0 && w1), "band_replace: NULL buffer");
+  band_replace_kernel<<<(unsigned)cdiv((int64_t)H * W, 256), 256, 0, as_stream(stream)>>>(
+      (const float2*)k0, (const float2*)kall, w0, w1, n, H, W, (float2*)kout, mask);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
 }

@@ -83,10 +83,16 @@ def motion_simulation2D(image_2d: torch.Tensor, n_movements: int):
 def make_slice(H: int, W: int, n_movements: int, slice_idx: int, device="cpu"):
     """Seeded synthetic slice: ground truth, corrupted k-space and the voted line flags
     (`mask.sum(0)/H > 0.2`, reference src/test/test_immoco.py:59-61 with the ground-truth mask
-    standing in for kLD-Net, whose weights are not available)."""
+    standing in for kLD-Net, whose weights are not available).  On a GPU device the corruption is
+    produced by the HIP motion simulator (utils/motion_utils.py, same host RNG draws, validated
+    against the reference's golden vectors); on the CPU by the torch restatement above."""
     seed = 1000 + int(slice_idx)
     gt = phantom(H, W, seed, device=device)
     torch.manual_seed(seed)
-    ksp, mask, rots, trans = motion_simulation2D(gt.clone(), n_movements)
+    if torch.device(device).type == "cuda":
+        from .utils.motion_utils import motion_simulation2D as sim_gpu
+        ksp, mask, rots, trans = sim_gpu(gt.clone(), n_movements)
+    else:
+        ksp, mask, rots, trans = motion_simulation2D(gt.clone(), n_movements)
     lines = mask.sum(0).div(H) > 0.2
     return {"gt": gt, "kspace": ksp, "lines": lines, "rotations": rots, "translations": trans}

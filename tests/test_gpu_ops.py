@@ -637,3 +637,18 @@ def test_config2_trajectory_vs_cpu_oracle(env, golden):
     assert 0.5 * ol[-1] <= float(np.median(finals)) <= 2.0 * ol[-1]
     assert abs(float(np.median(ps)) - float(g["psnr"][-1])) <= 1.0          # chaos-limited band
     assert max(ps) >= float(g["psnr"][-1]) - 0.75
+
+
+@pytest.mark.parametrize("tag", ["s32", "s64"])
+def test_motion_simulation_gpu_vs_reference_golden(env, golden, tag):
+    """the reference's motion simulator on the HIP kernels (same host RNG draws)."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd.utils.motion_utils import motion_simulation2D
+    g = golden("motion_sim")
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    ksp, mask, rot, tr = motion_simulation2D(torch.from_numpy(g[f"{tag}_img"]).cuda(), n_movements=int(g[f"{tag}_nm"]))
+    assert mask.dtype == torch.int64 and bool((mask == mask[:1]).all())
+    assert np.array_equal(mask[0].cpu().numpy().astype(np.uint8), g[f"{tag}_mask_row0"])     # bit-exact lines
+    assert np.array_equal(rot.numpy(), g[f"{tag}_rot"]) and np.array_equal(tr.numpy(), g[f"{tag}_tr"])
+    s = np.abs(g[f"{tag}_ksp"]).max()
+    np.testing.assert_allclose(ksp.cpu().numpy(), g[f"{tag}_ksp"], rtol=1e-3, atol=2e-5 * s)
