@@ -6,25 +6,27 @@
 // corner and feature, 2 x 131 M per iteration at 320x320 / 10 groups) runs at the
 // memory-side atomic rate and takes 12.9 ms per iteration (77 % of the step).
 //
-// Plan (once per solver): a transposed index ("CSR by slot"): for every table slot the
-// list of (m, row, col, corner) contributions, 4 bytes each, slot-sorted, built on the
-// GPU (count -> exclusive scan -> fill), plus a host-built list of work items that cover
-// <= SLOTS_PER_ITEM consecutive slots and <= ENTRIES_PER_ITEM entries each.
+// Plan (once per solver): a transposed index ("CSR by slot"): for every table slot the list of its
+// contributions, slot-sorted, built on the GPU (count -> hipCUB exclusive scan -> fill), plus a
+// host-built list of work items.  An entry is 8 bytes: {point (relative to its part) << 11 | slot
+// (relative to its 2048-slot block), interpolation weight fp32}.  Earlier versions stored 4 bytes
+// (corner | col | row | m) and recomputed slot and weight per entry from LDS axis tables: an
+// ablation on MI355X showed that this decode/hash/weight ALU work was 70 % of the kernel
+// (0.63 ms with, 0.45 ms without the gathers), so the plan now pays 4 more bytes of (otherwise
+// idle) HBM stream per entry to remove it.
 //
-// Backward (every iteration): one workgroup per work item streams its entries
-// (coalesced 4-B reads), recomputes slot + interpolation weight from per-level axis
-// tables held in LDS, gathers dL/denc (8 B, level slice is L2/MALL resident),
-// accumulates into an LDS tile of the gradient table (ds_add_f32), and flushes the
-// tile with contiguous float atomics (the fast 256-B shape; slots that straddle work
-// items are thereby summed correctly).
+// Backward (every iteration): one workgroup per work item; every thread owns 16 CONSECUTIVE
+// entries (eight coalesced 16-byte loads from a transposed chunk layout, next chunk prefetched),
+// gathers dL/denc (8 B, level slice
+// L2/MALL resident), sums equal-slot runs in registers and issues one LDS atomic per run into a
+// 2048-slot LDS tile; the tile is written out with plain stores (items that share a slot block -
+// only on the coarse dense levels - flush with contiguous atomics instead).
 //
 // L2 locality: the gather's working set is one level slice of dL/denc (8 B x points = 8 MB at
-// 320x320x10), twice an XCD's 4 MB L2, so v1 ran at Infinity-Cache speed (1.24 ms).  The plan
-// therefore splits the points into `n_parts` contiguous ranges, sorts entries by (level, part,
-// slot) and orders the work items so that workgroup index i (which lands on XCD i % 8) only
-// touches part (i % 8) % n_parts: every XCD keeps a 8/n_parts MB slice hot.  Each part writes its
-// own partial gradient table (plain stores; a (part, slot) pair belongs to exactly one work item
-// unless the slot is oversized); the Adam kernel sums the partial tables while reading them.
+// 320x320x10), twice an XCD's 4 MB L2.  The plan splits the points into `n_parts` contiguous
+// ranges, sorts entries by (level, part, slot) and orders the work items so that workgroup index i
+// (which lands on XCD i % 8) only touches part (i % 8) % n_parts: every XCD keeps a 8/n_parts MB
+// slice hot.  Each part writes its own partial gradient table; the Adam kernel sums them.
 #include <hipcub/hipcub.hpp>
 
 #include <vector>
@@ -33,15 +35,11 @@
 
 namespace immoco {
 
-constexpr int SLOTS_PER_ITEM = 2048;
+constexpr int SLOT_BITS = 11;
+constexpr int SLOTS_PER_ITEM = 1 << SLOT_BITS;  // 2048: aligned slot blocks
 constexpr int ENTRIES_PER_ITEM = 32768;
 
-// entry packing: corner [0,3) | col [3,13) | row [13,23) | m [23,28)
-__device__ __forceinline__ uint32_t pack_entry(uint32_t m, uint32_t r, uint32_t c, uint32_t corner) {
-  return corner | (c << 3) | (r << 13) | (m << 23);
-}
-
-// lattice index of dimension d for entry fields (m, r, c):
+// lattice index of dimension d for point fields (m, r, c):
 //   D == 3 (motion INR, make_grids order):  dim0 = m, dim1 = row, dim2 = col
 //   D == 2 (image INR, identy_grid order):  dim0 = col (x), dim1 = row (y)
 template <int D>
@@ -69,7 +67,7 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
                                                              int n_parts, int64_t part_size,
                                                              uint32_t* __restrict__ counts_or_cursor,
                                                              const uint32_t* __restrict__ offs,
-                                                             uint32_t* __restrict__ entries) {
+                                                             uint2* __restrict__ entries) {
   const int l = blockIdx.y;
   const int64_t n = (int64_t)nM * H * W;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -84,168 +82,139 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
   float fr[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) pos_fract(ax.a[d][li[d]], scale, cell[d], fr[d]);
+  const uint32_t part = (uint32_t)(p / part_size);
+  const uint32_t p_rel = (uint32_t)(p - (int64_t)part * part_size);
 #pragma unroll
   for (int corner = 0; corner < (1 << D); ++corner) {
     uint32_t cc[D];
+    float w = 1.0f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) cc[d] = cell[d] + ((corner >> d) & 1);
+    for (int d = 0; d < D; ++d) {
+      const bool hi = (corner >> d) & 1;
+      cc[d] = cell[d] + (hi ? 1u : 0u);
+      w *= hi ? fr[d] : 1.0f - fr[d];
+    }
+    const uint32_t idx = grid_index<D>(cc, size, res, hashed, pow2);
     // counter index ordered by (level, part, slot)
-    const uint32_t part = (uint32_t)(p / part_size);
-    const uint32_t slot = lv.offset[l] * (uint32_t)n_parts + part * size + grid_index<D>(cc, size, res, hashed, pow2);
-    const uint32_t pos = atomicAdd(counts_or_cursor + slot, 1u);
-    if (FILL) entries[offs[slot] + pos] = pack_entry(m, r, c, (uint32_t)corner);
+    const uint32_t key = lv.offset[l] * (uint32_t)n_parts + part * size + idx;
+    const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
+    if (FILL)
+      entries[offs[key] + pos] = make_uint2((p_rel << SLOT_BITS) | (idx & (SLOTS_PER_ITEM - 1)), __float_as_uint(w));
   }
 }
 
 struct BwdItem {
-  uint32_t e0, e1;    // entry range
-  uint32_t s0, ns;    // first global slot, number of slots covered
+  uint32_t e0, e1;       // range in the slot-sorted build array (plan build only)
+  uint32_t s0, ns;       // first global slot (block aligned within its level), number of slots
   uint32_t level;
-  uint32_t part_shared;  // part | (shared << 16): shared = the slot range also belongs to other items
+  uint32_t part_shared;  // part | (shared << 16): shared = the slot block also belongs to other items
+  uint32_t pe0, n_wc;    // start (in entries, multiple of 1024) and wave-chunk count in the final array
 };
 
+// Final entry layout: an item owns n_wc "wave chunks" of 1024 entries.  Inside a wave chunk the
+// entries are stored transposed, [j = 0..7][lane = 0..63] x 16 bytes, so that a wave's eight loads
+// are each 1 KiB contiguous (coalesced) while lane `lane` still receives the 16 CONSECUTIVE sorted
+// entries 16*lane .. 16*lane+15 of the chunk.  (Thread-contiguous 128-byte reads were measured
+// 25 % slower: each of the 8 loads touches 64 different lines.)  Chunks are padded with entries
+// {point 0, slot 0, weight 0}, which add 0 and need no masking.
+constexpr int WAVE_CHUNK = 1024;
+
+__global__ __launch_bounds__(256) void csr_permute_kernel(const BwdItem* __restrict__ items,
+                                                          const uint2* __restrict__ sorted, uint2* __restrict__ out) {
+  const BwdItem it = items[blockIdx.x];
+  const uint32_t n_e = it.e1 - it.e0, n_pad = it.n_wc * WAVE_CHUNK;
+  for (uint32_t s = threadIdx.x; s < n_pad; s += 256) {
+    const uint2 v = s < n_e ? sorted[it.e0 + s] : make_uint2(0u, 0u);
+    const uint32_t wc = s / WAVE_CHUNK, lane = (s % WAVE_CHUNK) / 16, k = s % 16;
+    out[(size_t)it.pe0 + (size_t)wc * WAVE_CHUNK + ((k >> 1) * 64 + lane) * 2 + (k & 1)] = v;
+  }
+}
+
 // ---- backward ----------------------------------------------------------------------
-// Entries are slot-sorted, so neighbouring entries mostly share a slot (runs of ~16 on the hashed
-// levels of the motion grid).  v1 fed them lane-by-lane into LDS atomics, which serialise on the
-// shared address (1.86 ms per iteration).  v2 staged 4096-entry tiles through LDS with two
-// barriers per tile and was latency-bound (rocprof: SQ_WAIT_ANY 61 % of wave cycles, 0.87 ms).
-// v3 (this kernel): every thread owns 16 CONSECUTIVE entries = four aligned 16-byte loads straight
-// from global memory (no staging, no barrier inside the loop; the next chunk is prefetched while
-// the current one is processed), sums equal-slot runs in registers and issues one LDS atomic per
-// run, so lanes of one wave-instruction hit different slots.
+// History (MI355X, 320x320x10): v1 lane-per-entry LDS atomics 1.86 ms; v2 LDS-staged tiles 0.87 ms
+// (latency-bound, SQ_WAIT_ANY 61 %); v3 per-thread runs of 16 entries, 4-byte entries decoded on
+// the fly 0.63 ms; v4 precomputed 8-byte entries, thread-contiguous loads 0.79 ms; v5 (this kernel)
+// the same in the transposed wave-chunk layout 0.59 ms.  Tried without gain: slot-pair entries that
+// share one gather between the two dim-0 corners (0.61 ms on v3), twin corners stored adjacently
+// (0.59 ms on v5).  rocprof: TA busy 94 %, TA_ADDR_STALLED_BY_TC 82 %, TCP_PENDING_STALL 280 M cycles
+// -> both gather kernels sit at the L1 miss-concurrency limit (~175 G L2 requests/s chip-wide).
 constexpr int EPT = 16;                  // entries per thread per chunk
 constexpr int CHUNK_ENTRIES = 256 * EPT;  // 4096
 
-template <int D>
-__global__ __launch_bounds__(256) void csr_bwd_kernel(Levels lv, AxisPtrs<D> ax, int H, int W, int64_t n_points,
+__global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
-                                                      const uint32_t* __restrict__ entries,
+                                                      const uint2* __restrict__ entries,
                                                       const float2* __restrict__ denc /*[L][n]*/,
                                                       float* __restrict__ dtable, int64_t part_stride,
                                                       int zeroed) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* acc = reinterpret_cast<float*>(smem);  // [2*SLOTS_PER_ITEM]
-  // per-axis tables indexed by ENTRY FIELD: col, row, m
-  const int n_col = ax.n[D == 3 ? 2 : 0], n_row = ax.n[1], n_m = D == 3 ? ax.n[0] : 0;
-  uint32_t* c_col = reinterpret_cast<uint32_t*>(acc + 2 * SLOTS_PER_ITEM);
-  uint32_t* c_row = c_col + n_col;
-  uint32_t* c_m = c_row + n_row;
-  float* f_col = reinterpret_cast<float*>(c_m + n_m);
-  float* f_row = f_col + n_col;
-  float* f_m = f_row + n_row;
-
+  __shared__ float acc[2 * SLOTS_PER_ITEM];
   const BwdItem it = items[blockIdx.x];
-  if (it.e0 >= it.e1) return;  // padding item of the XCD interleave
-  const int l = (int)it.level;
-  const float scale = lv.scale[l];
-  const uint32_t size = lv.size[l], res = lv.res[l];
-  const bool hashed = (lv.hashed >> l) & 1u, pow2 = (lv.pow2 >> l) & 1u;
-  const uint32_t slot_base = it.s0 - lv.offset[l];
+  if (it.n_wc == 0) return;  // padding item of the XCD interleave
   const int tid = threadIdx.x;
   for (int i = tid; i < 2 * (int)it.ns; i += 256) acc[i] = 0.f;
-  for (int i = tid; i < n_col; i += 256) pos_fract(ax.a[D == 3 ? 2 : 0][i], scale, c_col[i], f_col[i]);
-  for (int i = tid; i < n_row; i += 256) pos_fract(ax.a[1][i], scale, c_row[i], f_row[i]);
-  if (D == 3)
-    for (int i = tid; i < n_m; i += 256) pos_fract(ax.a[0][i], scale, c_m[i], f_m[i]);
   __syncthreads();
-  const float2* __restrict__ dl = denc + (int64_t)l * n_points;
-  // 16-byte aligned walk: start at e0 rounded down to a multiple of 4 entries and mask the strays
-  // (the entries allocation is padded, see csr_build_t)
-  const uint32_t a0 = it.e0 & ~3u;
-  const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(entries);
-  uint32_t base = a0 + (uint32_t)tid * EPT;
-  uint4 q[4];
+  const uint32_t part = it.part_shared & 0xFFFFu;
+  const float2* __restrict__ dl = denc + (int64_t)it.level * n_points + (int64_t)part * part_size;
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(entries + it.pe0);
+  uint4 q[EPT / 2];
+  if ((uint32_t)wave < it.n_wc) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) q[j] = base + 4u * j < it.e1 ? e4[(base >> 2) + j] : make_uint4(0, 0, 0, 0);
-  for (uint32_t cb = a0; cb < it.e1; cb += CHUNK_ENTRIES) {
-    uint32_t u[EPT];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u[4 * j] = q[j].x;
-      u[4 * j + 1] = q[j].y;
-      u[4 * j + 2] = q[j].z;
-      u[4 * j + 3] = q[j].w;
-    }
-    const uint32_t my = base;
-    base += CHUNK_ENTRIES;
-    if (cb + CHUNK_ENTRIES < it.e1) {  // prefetch the next chunk
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = base + 4u * j < it.e1 ? e4[(base >> 2) + j] : make_uint4(0, 0, 0, 0);
-    }
-    uint32_t loc[EPT];
+    for (int j = 0; j < EPT / 2; ++j) q[j] = e4[(size_t)wave * (WAVE_CHUNK / 2) + j * 64 + lane];
+  }
+  for (uint32_t wc = wave; wc < it.n_wc; wc += 4) {
+    uint32_t key[EPT];
     float wt[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT / 2; ++j) {
+      key[2 * j] = q[j].x;
+      wt[2 * j] = __uint_as_float(q[j].y);
+      key[2 * j + 1] = q[j].z;
+      wt[2 * j + 1] = __uint_as_float(q[j].w);
+    }
+    if (wc + 4 < it.n_wc) {  // prefetch this wave's next chunk
+#pragma unroll
+      for (int j = 0; j < EPT / 2; ++j) q[j] = e4[(size_t)(wc + 4) * (WAVE_CHUNK / 2) + j * 64 + lane];
+    }
     float2 g[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const uint32_t idx = my + k;
-      const bool ok = idx >= it.e0 && idx < it.e1;
-      const uint32_t uu = ok ? u[k] : 0u;
-      const uint32_t corner = uu & 7u, c = (uu >> 3) & 1023u, r = (uu >> 13) & 1023u, m = (uu >> 23) & 31u;
-      uint32_t cc[D];
-      float w;
-      if (D == 3) {
-        const uint32_t b0 = corner & 1u, b1 = (corner >> 1) & 1u, b2 = (corner >> 2) & 1u;
-        cc[0] = c_m[m] + b0;
-        cc[1] = c_row[r] + b1;
-        if (D > 2) cc[2] = c_col[c] + b2;
-        const float f0 = f_m[m], f1 = f_row[r], f2 = f_col[c];
-        w = (b0 ? f0 : 1.f - f0) * (b1 ? f1 : 1.f - f1) * (b2 ? f2 : 1.f - f2);
-      } else {
-        const uint32_t b0 = corner & 1u, b1 = (corner >> 1) & 1u;
-        cc[0] = c_col[c] + b0;
-        cc[1] = c_row[r] + b1;
-        const float f0 = f_col[c], f1 = f_row[r];
-        w = (b0 ? f0 : 1.f - f0) * (b1 ? f1 : 1.f - f1);
-      }
-      loc[k] = ok ? grid_index<D>(cc, size, res, hashed, pow2) - slot_base : 0xFFFFFFFFu;
-      wt[k] = ok ? w : 0.f;
-      g[k] = dl[((int64_t)m * H + r) * W + c];
-    }
+    for (int k = 0; k < EPT; ++k) g[k] = dl[key[k] >> SLOT_BITS];
     // run-length accumulate
-    uint32_t cur = loc[0];
+    uint32_t cur = key[0] & (SLOTS_PER_ITEM - 1);
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (loc[k] != cur) {
-        if (cur < it.ns) {
-          atomicAdd(&acc[2 * cur], s0);
-          atomicAdd(&acc[2 * cur + 1], s1);
-        }
-        cur = loc[k];
+      const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1);
+      if (loc != cur) {
+        atomicAdd(&acc[2 * cur], s0);
+        atomicAdd(&acc[2 * cur + 1], s1);
+        cur = loc;
         s0 = s1 = 0.f;
       }
       s0 = fmaf(wt[k], g[k].x, s0);
       s1 = fmaf(wt[k], g[k].y, s1);
     }
-    if (cur < it.ns) {  // (masked entries carry 0xFFFFFFFF and are dropped)
-      atomicAdd(&acc[2 * cur], s0);
-      atomicAdd(&acc[2 * cur + 1], s1);
-    }
+    atomicAdd(&acc[2 * cur], s0);
+    atomicAdd(&acc[2 * cur + 1], s1);
   }
   __syncthreads();
-  float* __restrict__ out = dtable + (size_t)(it.part_shared & 0xFFFFu) * part_stride + (size_t)it.s0 * 2;
+  float* __restrict__ out = dtable + (size_t)part * part_stride + (size_t)it.s0 * 2;
   if (it.part_shared >> 16) {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
       const float v = acc[i];
       if (v != 0.f) unsafeAtomicAdd(out + i, v);
     }
-  } else {
+  } else if (zeroed) {
     // exclusive owner of these (part, slot) pairs: no atomics.  Solver mode (`zeroed`): the tile is
     // OVERWRITTEN every iteration (zeros included), so nobody has to clear it (Adam's fused
     // zero_grad skips these ranges: 16 B/param less HBM traffic); op-level mode accumulates.
-    if (zeroed) {
-      for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = acc[i];
-    } else {
-      for (int i = tid; i < 2 * (int)it.ns; i += 256) {
-        const float v = acc[i];
-        if (v != 0.f) out[i] += v;
-      }
+    for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = acc[i];
+  } else {
+    for (int i = tid; i < 2 * (int)it.ns; i += 256) {
+      const float v = acc[i];
+      if (v != 0.f) out[i] += v;
     }
   }
-}
-
-static size_t csr_bwd_smem(int n_col, int n_row, int n_m) {
-  return (size_t)2 * SLOTS_PER_ITEM * 4 + (size_t)(n_col + n_row + n_m) * 8;
 }
 
 // ---- host side -------------------------------------------------------------------------
@@ -257,7 +226,7 @@ struct CsrPlan {
   int64_t part_size = 0;
   const float* axes[3] = {nullptr, nullptr, nullptr};
   int32_t axn[3] = {0, 0, 0};
-  uint32_t* entries = nullptr;
+  uint2* entries = nullptr;
   BwdItem* items = nullptr;
   uint32_t n_items = 0;
   uint64_t n_entries = 0;
@@ -302,36 +271,30 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   IMMOCO_CHECK_HIP(hipStreamSynchronize(st));
   pl->n_entries = h_offs[n_cnt];
   IMMOCO_REQUIRE(pl->n_entries == (uint64_t)n * lv.n_levels * (1u << D), "csr plan: entry count mismatch");
-  IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->entries, (size_t)pl->n_entries * 4 + 64));  // + slack for aligned 16-B reads
+  uint2* sorted = nullptr;  // slot-sorted build array, permuted into the final layout below
+  IMMOCO_CHECK_HIP(hipMalloc((void**)&sorted, (size_t)pl->n_entries * 8));
   IMMOCO_CHECK_HIP(hipMemsetAsync(counts, 0, (n_cnt + 1) * 4, st));
   csr_count_fill_kernel<D, true><<<grid, 256, 0, st>>>(lv, ax, pl->nM, pl->H, pl->W, NP, pl->part_size, counts, offs,
-                                                      pl->entries);
+                                                      sorted);
   IMMOCO_LAUNCH_CHECK();
-  // Work items per part: consecutive slots of one (level, part), bounded in slots and entries; a
-  // slot with more entries than ENTRIES_PER_ITEM (coarse dense levels) is split over several
+  // Work items per part: one aligned block of SLOTS_PER_ITEM slots of one (level, part); a block
+  // with more than ENTRIES_PER_ITEM entries (coarse dense levels) is split by entries over several
   // items, which then flush with atomics ("shared").
   std::vector<std::vector<BwdItem>> per_part(NP);
   for (int l = 0; l < lv.n_levels; ++l) {
     for (int q = 0; q < NP; ++q) {
       const size_t cb = (size_t)lv.offset[l] * NP + (size_t)q * lv.size[l];  // counter index of slot 0
-      uint32_t s = 0;
-      const uint32_t s_end = lv.size[l];
-      while (s < s_end) {
-        const uint32_t e0 = h_offs[cb + s];
-        uint32_t s1 = s;
-        while (s1 < s_end && (s1 - s) < (uint32_t)SLOTS_PER_ITEM && (h_offs[cb + s1 + 1] - e0) <= (uint32_t)ENTRIES_PER_ITEM)
-          ++s1;
-        if (s1 == s) {
-          const uint32_t e_end = h_offs[cb + s + 1];
-          for (uint32_t e = e0; e < e_end; e += ENTRIES_PER_ITEM)
-            per_part[q].push_back({e, std::min<uint32_t>(e + ENTRIES_PER_ITEM, e_end), lv.offset[l] + s, 1u,
-                                   (uint32_t)l, (uint32_t)q | (1u << 16)});
-          pl->shared_slot_end = std::max(pl->shared_slot_end, lv.offset[l] + s + 1);
-          s = s + 1;
+      for (uint32_t s = 0; s < lv.size[l]; s += SLOTS_PER_ITEM) {
+        const uint32_t ns = std::min<uint32_t>(SLOTS_PER_ITEM, lv.size[l] - s);
+        const uint32_t e0 = h_offs[cb + s], e1 = h_offs[cb + s + ns];
+        if (e1 == e0) continue;
+        if (e1 - e0 <= (uint32_t)ENTRIES_PER_ITEM) {
+          per_part[q].push_back({e0, e1, lv.offset[l] + s, ns, (uint32_t)l, (uint32_t)q, 0u, 0u});
         } else {
-          if (h_offs[cb + s1] > e0)
-            per_part[q].push_back({e0, h_offs[cb + s1], lv.offset[l] + s, s1 - s, (uint32_t)l, (uint32_t)q});
-          s = s1;
+          for (uint32_t e = e0; e < e1; e += ENTRIES_PER_ITEM)
+            per_part[q].push_back({e, std::min<uint32_t>(e + ENTRIES_PER_ITEM, e1), lv.offset[l] + s, ns, (uint32_t)l,
+                                   (uint32_t)q | (1u << 16), 0u, 0u});
+          pl->shared_slot_end = std::max(pl->shared_slot_end, lv.offset[l] + s + ns);
         }
       }
     }
@@ -346,7 +309,7 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
     const int xcds_per_part = 8 / NP;
     size_t rounds = 0;
     for (int q = 0; q < NP; ++q) rounds = std::max(rounds, (per_part[q].size() + xcds_per_part - 1) / xcds_per_part);
-    items.assign(rounds * 8, BwdItem{0, 0, 0, 0, 0, 0});
+    items.assign(rounds * 8, BwdItem{0, 0, 0, 0, 0, 0, 0, 0});
     for (int x = 0; x < 8; ++x) {
       const int q = x % NP, lane = x / NP;
       for (size_t k = 0; k < rounds; ++k) {
@@ -355,22 +318,41 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
       }
     }
   }
+  // final (padded, transposed) positions
+  uint64_t total = 0;
+  for (BwdItem& it : items) {
+    it.n_wc = (it.e1 - it.e0 + WAVE_CHUNK - 1) / WAVE_CHUNK;
+    it.pe0 = (uint32_t)total;
+    total += (uint64_t)it.n_wc * WAVE_CHUNK;
+  }
+  IMMOCO_REQUIRE(total < 0xFFFFFF00ull, "csr plan: padded entry count exceeds uint32");
   pl->n_items = (uint32_t)items.size();
   IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->items, std::max<size_t>(1, items.size()) * sizeof(BwdItem)));
   IMMOCO_CHECK_HIP(hipMemcpyAsync(pl->items, items.data(), items.size() * sizeof(BwdItem), hipMemcpyHostToDevice, st));
+  IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->entries, std::max<uint64_t>(total, 1) * 8));
+  if (pl->n_items) {
+    csr_permute_kernel<<<pl->n_items, 256, 0, st>>>(pl->items, sorted, pl->entries);
+    IMMOCO_LAUNCH_CHECK();
+  }
   IMMOCO_CHECK_HIP(hipStreamSynchronize(st));
-  pl->bytes = (int64_t)pl->n_entries * 4 + (int64_t)items.size() * sizeof(BwdItem);
+  pl->bytes = (int64_t)total * 8 + (int64_t)items.size() * sizeof(BwdItem);
+  hipFree(sorted);
   hipFree(counts);
   hipFree(offs);
   hipFree(tmp);
   return IMMOCO_OK;
 }
 
-// axes: device pointers that must stay valid and constant for the plan's lifetime.
+// axes: device pointers, only read while the plan is built.
 int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* axes, const int32_t* axn,
                    int n_parts, CsrPlan** out, hipStream_t st) {
-  IMMOCO_REQUIRE(W <= 1024 && H <= 1024 && nM <= 32, "csr plan: lattice %dx%dx%d exceeds the entry packing", nM, H, W);
   IMMOCO_REQUIRE(n_parts == 1 || n_parts == 2 || n_parts == 4 || n_parts == 8, "csr plan: n_parts must divide 8");
+  const int64_t n = (int64_t)nM * H * W;
+  const int64_t part_size = cdiv(n, n_parts);
+  IMMOCO_REQUIRE(part_size <= (1ll << (32 - SLOT_BITS)),
+                 "csr plan: %lld points per part exceed the %d-bit entry field (use more parts)", (long long)part_size,
+                 32 - SLOT_BITS);
+  IMMOCO_REQUIRE((uint64_t)n * lv.n_levels * (1u << lv.dims) < 0xFFFFFF00ull, "csr plan: too many entries for uint32");
   CsrPlan* pl = new CsrPlan();
   pl->dims = lv.dims;
   pl->lv = lv;
@@ -378,7 +360,7 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
   pl->H = H;
   pl->W = W;
   pl->n_parts = n_parts;
-  pl->part_size = cdiv((int64_t)nM * H * W, n_parts);
+  pl->part_size = part_size;
   for (int d = 0; d < lv.dims; ++d) {
     pl->axes[d] = axes[d];
     pl->axn[d] = axn[d];
@@ -397,30 +379,14 @@ int csr_plan_parts(const CsrPlan* p) { return p ? p->n_parts : 1; }
 uint32_t csr_plan_shared_slot_end(const CsrPlan* p) { return p ? p->shared_slot_end : 0; }
 
 // dtable: n_parts partial tables, `part_stride` floats apart.  zeroed != 0: the caller guarantees
-// that the buffers hold zeros (plain stores); otherwise the results are accumulated.
+// that the buffers hold zeros or stale values of the same plan (plain stores); otherwise the
+// results are accumulated.
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride, int zeroed,
                    hipStream_t st) {
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
-  if (pl->dims == 3) {
-    AxisPtrs<3> ax{};
-    for (int d = 0; d < 3; ++d) {
-      ax.a[d] = pl->axes[d];
-      ax.n[d] = pl->axn[d];
-    }
-    csr_bwd_kernel<3><<<pl->n_items, 256, csr_bwd_smem(pl->W, pl->H, pl->nM), st>>>(
-        pl->lv, ax, pl->H, pl->W, n, pl->items, pl->entries, (const float2*)denc_level_major, dtable, part_stride,
-        zeroed);
-  } else {
-    AxisPtrs<2> ax{};
-    for (int d = 0; d < 2; ++d) {
-      ax.a[d] = pl->axes[d];
-      ax.n[d] = pl->axn[d];
-    }
-    csr_bwd_kernel<2><<<pl->n_items, 256, csr_bwd_smem(pl->W, pl->H, 0), st>>>(
-        pl->lv, ax, pl->H, pl->W, n, pl->items, pl->entries, (const float2*)denc_level_major, dtable, part_stride,
-        zeroed);
-  }
+  csr_bwd_kernel<<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,
+                                              (const float2*)denc_level_major, dtable, part_stride, zeroed);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
