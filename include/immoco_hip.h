@@ -237,6 +237,12 @@ int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, const int32
 /* Average per-kernel device time (ms) of the last immoco_solver_profile call, for
  * bench.py's roofline line.  names: [host] array of const char*; returns count. */
 int immoco_solver_phase_times(immoco_solver_t s, const char** names, float* ms, int32_t max_n);
+/* Duration (ms) of the dominant kernel (motion-grid encode backward) in the LAST iteration of the
+ * last solve, from HIP events recorded around it on its stream (valid after an EAGER solve: HIP does
+ * not report elapsed time for events recorded as graph nodes); < 0 if unavailable. */
+float immoco_solver_dominant_kernel_ms(immoco_solver_t s);
+/* Run-time switch between graph replay (1) and eager launches on the same streams (0). */
+int immoco_solver_set_graph(immoco_solver_t s, int32_t use_graph);
 /* 1 when the last solve replayed a captured hipGraph, 0 when it launched eagerly. */
 int immoco_solver_graph_active(immoco_solver_t s);
 

@@ -89,6 +89,8 @@ PROTOTYPES = {
     "immoco_grid_plan_bwd": (C.c_int, [_P, _P, _P, _P]),
     "immoco_solver_phase_times": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _I32]),
     "immoco_solver_graph_active": (C.c_int, [_P]),
+    "immoco_solver_dominant_kernel_ms": (C.c_float, [_P]),
+    "immoco_solver_set_graph": (C.c_int, [_P, _I32]),
 }
 
 

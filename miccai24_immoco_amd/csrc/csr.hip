@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void csr_permute_kernel(const BwdItem* __restr
 constexpr int EPT = 16;                  // entries per thread per chunk
 constexpr int CHUNK_ENTRIES = 256 * EPT;  // 4096
 
+template <int DIMS>  // DIMS only names the instantiation (2: image grid, 3: motion grid) in profiles
 __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
                                                       const uint2* __restrict__ entries,
@@ -385,8 +386,12 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
                    hipStream_t st) {
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
-  csr_bwd_kernel<<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,
-                                              (const float2*)denc_level_major, dtable, part_stride, zeroed);
+  if (pl->dims == 3)
+    csr_bwd_kernel<3><<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,
+                                                   (const float2*)denc_level_major, dtable, part_stride, zeroed);
+  else
+    csr_bwd_kernel<2><<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,
+                                                   (const float2*)denc_level_major, dtable, part_stride, zeroed);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

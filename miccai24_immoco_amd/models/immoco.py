@@ -227,6 +227,14 @@ class _SolverHandle:
         n = L.lib().immoco_solver_phase_times(self.handle, names, ms, 64)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def set_graph(self, on: bool):
+        L.check(L.lib().immoco_solver_set_graph(self.handle, 1 if on else 0), "solver_set_graph")
+
+    @property
+    def dominant_kernel_ms(self):
+        """Duration of the motion-grid encode backward in the last iteration of the last solve (in-graph events)."""
+        return float(L.lib().immoco_solver_dominant_kernel_ms(self.handle))
+
     @property
     def graph_active(self):
         return bool(L.lib().immoco_solver_graph_active(self.handle))
