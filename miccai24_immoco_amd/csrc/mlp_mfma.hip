@@ -1,77 +1,38 @@
-// MFMA implementation of the bias-free MLP 32 -> HID -> 2 (forward and backward).
+// Matrix-core implementation of the bias-free MLP 32 -> HID -> 2 (forward and backward) with
+// gfx950's f32-input MFMA, v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain, no
+// conversion of the operands) at the fp32 vector rate.
 //
-// Why: the fp32 VALU kernels (mlp.hip) spend 1.15 + 0.53 ms per iteration in the backward pass
-// (rocprof, MI355X) - the weight-gradient outer products need a reduction over points that a
-// lane-per-point mapping can only do through LDS broadcasts.  Every product of the MLP is a small
-// dense GEMM with K = 32 or 64, so it belongs on the matrix cores.  gfx950's f32-input MFMA runs
-// at the VALU rate (1/16 of bf16), so fp32 operands are split into THREE bf16 terms
-// (x = x1 + x2 + x3, 8+8+8 mantissa bits) and each product is evaluated with the six MFMAs whose
-// terms are >= 2^-24 relative: x1y1 + x1y2 + x2y1 + x1y3 + x2y2 + x3y1, accumulated in fp32.
-// Result: fp32-equivalent accuracy at 16/6 of the fp32 matrix rate, and - more importantly - the
-// reductions over points and over hidden units happen inside the MFMA K dimension.
+// Why MFMA although its fp32 rate equals the VALU's: every product of this MLP is a small dense
+// GEMM (K = 32 features, 32 hidden units or 32 points), and three of them reduce over the lane
+// dimension of a lane-per-point layout (dW1, dW2 over points; d enc over hidden units).  The fp32
+// VALU kernels (mlp.hip) did those reductions through LDS broadcasts: 1.15 + 0.53 ms per iteration
+// (rocprof, MI355X).  A first matrix-core version split fp32 operands into three bf16 terms (six
+// v_mfma_f32_32x32x16_bf16 per product, fp32-equivalent): 0.245 + 0.141 ms backward, 0.082 + 0.024
+// forward, VALU-issue bound (rocprof: 2400 VALU instructions per 32-point tile, a third of them
+// operand splitting).  This f32-MFMA version needs no splitting and is bit-exact fp32:
+// 0.237 + 0.143 ms backward, 0.101 + 0.036 ms forward - the same speed within 5 %, so the exact
+// one is kept.  Both are latency/issue bound at 1-2 waves per SIMD, far from the MFMA pipe.
 //
-// One wave owns a tile of 32 points.  v_mfma_f32_32x32x16_bf16 fragment maps (cdna guide §3):
-//   A: lane l (r = l&31, h = l>>5) holds A[row r][k = 8h + i], i = 0..7
-//   B: lane l holds B[k = 8h + i][col r]
-//   D: reg g of lane l holds D[row (g&3) + 8(g>>2) + 4h][col r]
-// A result tile X (rows in registers, column on the lane) feeds the next MFMA as B operand of
-// k-step s with its registers 8s..8s+7 (k order 16s + 8(i>>2) + 4h + (i&3)); the other operand is
-// loaded in that same k order.  Both layouts of the hidden tile are computed (MFMAs are cheap):
-//   layout 1  pre [hidden][point] = W1 . enc^T      -> d enc^T = W1^T . dpre        (sum over hidden)
-//   layout 2  pre'[point][hidden] = enc . W1^T      -> dW1^T   = enc^T . dpre'      (sum over points)
-//                                                     dW2^T   = dout^T . h'        (sum over points)
-// so no fp32 tile is ever transposed through LDS.  Pre-split weight fragments live in LDS.
+// One wave owns a tile of 32 points.  Fragment maps of v_mfma_f32_32x32x2_f32 (cdna guide §3),
+// lane l, r = l & 31, h = l >> 5:
+//   A: one float A[row r][k = h]      B: one float B[k = h][col r]
+//   D: reg g holds D[row (g&3) + 8(g>>2) + 4h][col r]
+// A result tile X (rows in registers, column on the lane) is the B operand of a following product
+// that sums over X's rows WITHOUT any data movement: k-step g takes register g, i.e. the row pair
+// (drow(g,0), drow(g,1)); the A operand is simply loaded in that k order.
+//   layout 1  pre [hidden][point] = W1 . enc^T          -> d enc^T = W1^T . dpre      (sum over hidden)
+//   layout 2  h'  [point][hidden] = transpose(h) via LDS -> dW1^T  = enc^T . dpre'    (sum over points)
+//                                                          dW2^T  = dout^T . h'      (sum over points)
+// Weight fragments live in LDS (built once per workgroup); weight gradients stay in accumulator
+// registers across a wave's tiles and are flushed once with 256-byte contiguous atomics.
 #include "kernels.hpp"
 
 namespace immoco {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-struct Frag3 {  // three bf16 terms of one 8-element fp32 fragment
-  u32x4 h, m, l;
-};
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  bf16x2 v = {(__bf16)a, (__bf16)b};
-  return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ float lo_f(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_f(uint32_t p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
-
-// split 8 floats into 3 bf16 terms each
-__device__ __forceinline__ Frag3 split3(const float (&x)[8]) {
-  Frag3 f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a = x[2 * q], b = x[2 * q + 1];
-    const uint32_t ph = pack_bf16(a, b);
-    const float ra = a - lo_f(ph), rb = b - hi_f(ph);
-    const uint32_t pm = pack_bf16(ra, rb);
-    const float qa = ra - lo_f(pm), qb = rb - hi_f(pm);
-    const uint32_t pl = pack_bf16(qa, qb);
-    f.h[q] = ph;
-    f.m[q] = pm;
-    f.l[q] = pl;
-  }
-  return f;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                 0, 0);
-}
-
-// acc += A . B with fp32-equivalent accuracy (six bf16 MFMAs, small terms first)
-__device__ __forceinline__ void mfma6(f32x16& acc, const Frag3& a, const Frag3& b) {
-  acc = mfma_bf16(a.l, b.h, acc);
-  acc = mfma_bf16(a.m, b.m, acc);
-  acc = mfma_bf16(a.h, b.l, acc);
-  acc = mfma_bf16(a.m, b.h, acc);
-  acc = mfma_bf16(a.h, b.m, acc);
-  acc = mfma_bf16(a.h, b.h, acc);
+__device__ __forceinline__ f32x16 mfma32(float a, float b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
 // row index of D register g for lane half h
@@ -91,43 +52,60 @@ template <int ACT>
 __device__ __forceinline__ float act_f(float pre) {
   return ACT == IMMOCO_ACT_RELU ? fmaxf(pre, 0.f) : tanh_fast(pre);
 }
+// derivative from the activation VALUE (relu: h > 0 <=> pre > 0; tanh: 1 - h^2)
 template <int ACT>
-__device__ __forceinline__ float act_d(float pre, float hv) {
-  return ACT == IMMOCO_ACT_RELU ? (pre > 0.f ? 1.f : 0.f) : 1.f - hv * hv;
+__device__ __forceinline__ float act_d(float hv) {
+  return ACT == IMMOCO_ACT_RELU ? (hv > 0.f ? 1.f : 0.f) : 1.f - hv * hv;
 }
 
-// LDS image of pre-split weight fragments: frag index f, term t (0 h,1 m,2 l): [f][t][lane] u32x4
-__device__ __forceinline__ void lds_store_frag(u32x4* base, int f, int lane, const Frag3& v) {
-  base[(f * 3 + 0) * 64 + lane] = v.h;
-  base[(f * 3 + 1) * 64 + lane] = v.m;
-  base[(f * 3 + 2) * 64 + lane] = v.l;
-}
-__device__ __forceinline__ Frag3 lds_load_frag(const u32x4* base, int f, int lane) {
-  Frag3 v;
-  v.h = base[(f * 3 + 0) * 64 + lane];
-  v.m = base[(f * 3 + 1) * 64 + lane];
-  v.l = base[(f * 3 + 2) * 64 + lane];
-  return v;
-}
+constexpr int TLD = 36;  // row length of the per-wave 32x32 transpose tiles (conflict-free b32 writes / b128 reads)
 
-// fragment of the point tile: element i = in[point p][feature 16*ks + 8h + i] (0 beyond n).
-// The loads are UNCONDITIONAL on a clamped address and masked afterwards: a load under a divergent
-// `if` gets its own basic block and its own s_waitcnt, which serialises the whole tile prologue.
-__device__ __forceinline__ void load_enc_frag(const float* in, int64_t ps, int64_t ls, int64_t p, int64_t n, int ks,
-                                              int h, float (&x)[8]) {
+// B fragments of the point tile: eb[s] = in[point p][feature 2s + h] (0 beyond n).  Unconditional
+// loads on a clamped address (a load under a divergent `if` gets its own basic block and wait).
+__device__ __forceinline__ void load_enc_b(const float* in, int64_t ps, int64_t ls, int64_t p, int64_t n, int h,
+                                           float (&eb)[16]) {
   const int64_t pc = p < n ? p : n - 1;
   const float m = p < n ? 1.f : 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int level = 8 * ks + 4 * h + q;
-    const float2 v = *reinterpret_cast<const float2*>(in + pc * ps + (int64_t)level * ls);
-    x[2 * q] = v.x * m;
-    x[2 * q + 1] = v.y * m;
+  for (int s = 0; s < 16; ++s) eb[s] = in[pc * ps + (int64_t)s * ls + h] * m;
+}
+
+// LDS weight fragments: AW[jt][s4][lane] float4 = W1[jt*32 + r][2*(4*s4+i) + h], i = 0..3
+//                       AWT[jt][g4][lane] float4 = W1[jt*32 + drow(4*g4+i, h)][r]
+template <int HID>
+__device__ __forceinline__ void build_weight_frags(const float* __restrict__ w1, float4* aw, float4* awt, int tid) {
+  constexpr int NJT = HID / 32;
+  for (int e = tid; e < NJT * 4 * 64; e += 256) {
+    const int lane = e & 63, q4 = (e >> 6) & 3, jt = e >> 8;
+    const int r = lane & 31, h = lane >> 5;
+    float v[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = w1[(jt * 32 + r) * 32 + 2 * (4 * q4 + i) + h];
+      t[i] = w1[(jt * 32 + drow(4 * q4 + i, h)) * 32 + r];
+    }
+    aw[e] = make_float4(v[0], v[1], v[2], v[3]);
+    if (awt) awt[e] = make_float4(t[0], t[1], t[2], t[3]);
   }
+}
+
+// pre[hidden][point] tile of one jt
+__device__ __forceinline__ f32x16 pre_tile(const float4* aw, int jt, int lane, const float (&eb)[16]) {
+  f32x16 pre = {0.f};
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const float4 a = aw[(jt * 4 + s4) * 64 + lane];
+    pre = mfma32(a.x, eb[4 * s4], pre);
+    pre = mfma32(a.y, eb[4 * s4 + 1], pre);
+    pre = mfma32(a.z, eb[4 * s4 + 2], pre);
+    pre = mfma32(a.w, eb[4 * s4 + 3], pre);
+  }
+  return pre;
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward: out[p][0..1] = W2 . act(W1 . enc[p])
+// (Forcing 4 waves/SIMD with a register cap spills and is slower: 0.133 vs 0.101 ms.)
 template <int HID, int ACT>
 __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restrict__ in, int64_t ps, int64_t ls,
                                                            int64_t n, const float* __restrict__ w1,
@@ -135,45 +113,27 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restri
                                                            int64_t n_tiles) {
   constexpr int NJT = HID / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* aw = reinterpret_cast<u32x4*>(smem);                          // [NJT*2][3][64]
-  float* w2s = reinterpret_cast<float*>(aw + NJT * 2 * 3 * 64);         // [2][HID]
+  float4* aw = reinterpret_cast<float4*>(smem);                 // [NJT][4][64]
+  float* w2s = reinterpret_cast<float*>(aw + NJT * 4 * 64);     // [2][HID]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  // build the weight fragments once per block: wave w handles fragments w, w+4, ...
-  for (int f = wave; f < NJT * 2; f += 4) {
-    const int jt = f >> 1, ks = f & 1;
-    float x[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = w1[(jt * 32 + r) * 32 + ks * 16 + 8 * h + i];
-    lds_store_frag(aw, f, lane, split3(x));
-  }
+  build_weight_frags<HID>(w1, aw, nullptr, threadIdx.x);
   for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = w2[i];
   __syncthreads();
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
-  // software pipeline: the next tile's raw operands are in flight while this one is computed
-  float nx[2][8];
-  if (wave_id < n_tiles) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) load_enc_frag(in, ps, ls, wave_id * 32 + r, n, ks, h, nx[ks]);
-  }
+  float nx[16];  // software pipeline: the next tile's operands are in flight while this one is computed
+  if (wave_id < n_tiles) load_enc_b(in, ps, ls, wave_id * 32 + r, n, h, nx);
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
     const int64_t p = t * 32 + r;
-    const bool valid = p < n;
-    Frag3 eb[2];
+    float eb[16];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) eb[ks] = split3(nx[ks]);
-    if (t + n_waves < n_tiles) {
-      const int64_t pn = (t + n_waves) * 32 + r;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) load_enc_frag(in, ps, ls, pn, n, ks, h, nx[ks]);
-    }
+    for (int s = 0; s < 16; ++s) eb[s] = nx[s];
+    if (t + n_waves < n_tiles) load_enc_b(in, ps, ls, (t + n_waves) * 32 + r, n, h, nx);
     float o0 = 0.f, o1 = 0.f;
 #pragma unroll 2
     for (int jt = 0; jt < NJT; ++jt) {
-      f32x16 pre = {0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) mfma6(pre, lds_load_frag(aw, jt * 2 + ks, lane), eb[ks]);
+      const f32x16 pre = pre_tile(aw, jt, lane, eb);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const float4 wa = *reinterpret_cast<const float4*>(w2s + jt * 32 + 8 * a + 4 * h);
@@ -186,7 +146,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restri
     }
     o0 += __shfl_xor(o0, 32, 64);
     o1 += __shfl_xor(o1, 32, 64);
-    if (valid && h == 0) *reinterpret_cast<float2*>(out + p * 2) = make_float2(o0, o1);
+    if (p < n && h == 0) *reinterpret_cast<float2*>(out + p * 2) = make_float2(o0, o1);
   }
 }
 
@@ -201,26 +161,17 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
                                                            int64_t n_tiles, int64_t dout_plane) {
   constexpr int NJT = HID / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* aw = reinterpret_cast<u32x4*>(smem);                  // W1 fragments        [NJT*2][3][64]
-  u32x4* awt = aw + NJT * 2 * 3 * 64;                          // W1^T fragments      [NJT*2][3][64]
-  float* w2s = reinterpret_cast<float*>(awt + NJT * 2 * 3 * 64);  // [2][HID]
-  float* dos_all = w2s + 2 * HID;                              // per wave [32][2] dout staging
-  float* tr_all = dos_all + 4 * 64;                            // per wave [32][36] transpose tile
+  float4* aw = reinterpret_cast<float4*>(smem);                  // W1 fragments    [NJT][4][64]
+  float4* awt = aw + NJT * 4 * 64;                               // W1^T fragments  [NJT][4][64]
+  float* w2s = reinterpret_cast<float*>(awt + NJT * 4 * 64);     // [2][HID]
+  float* dos_all = w2s + 2 * HID;                                // per wave [32][2] dout staging
+  float* tr_all = dos_all + 4 * 64;                              // per wave two [32][TLD] transpose tiles
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   float* dos = dos_all + wave * 64;
-  float* tr = tr_all + wave * 32 * 36;
-  for (int f = wave; f < NJT * 2; f += 4) {
-    const int jt = f >> 1, s = f & 1;
-    float x[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = w1[(jt * 32 + r) * 32 + s * 16 + 8 * h + i];
-    lds_store_frag(aw, f, lane, split3(x));
-    // W1^T fragment in accumulator-k order: element i = W1[jt*32 + 16s + 8(i>>2) + 4h + (i&3)][k = r]
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = w1[(jt * 32 + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)) * 32 + r];
-    lds_store_frag(awt, f, lane, split3(x));
-  }
+  float* tr = tr_all + wave * 2 * 32 * TLD;   // h tile (and the final dW1 flush)
+  float* te = tr + 32 * TLD;                  // enc tile
+  build_weight_frags<HID>(w1, aw, awt, threadIdx.x);
   for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = w2[i];
   __syncthreads();
 
@@ -233,67 +184,51 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
   }
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
-  // software pipeline: raw operands of the NEXT tile are loaded while the current one is computed
-  float nx_e[2][8], nx_t[2][8];
+  float nx[16];
   float2 nx_d = make_float2(0.f, 0.f);
   auto load_raw = [&](int64_t tt) {
-    const int64_t q0 = tt * 32, q = q0 + r;
+    const int64_t q = tt * 32 + r;
     const int64_t qc = q < n ? q : n - 1;
     const float mq = q < n ? 1.f : 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) load_enc_frag(in, ps, ls, q, n, ks, h, nx_e[ks]);
+    load_enc_b(in, ps, ls, q, n, h, nx);
     if (dout_plane) {  // wave-uniform
       nx_d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
     } else {
       const float2 dv = *reinterpret_cast<const float2*>(dout + qc * 2);
       nx_d = make_float2(dv.x * mq, dv.y * mq);
     }
-    // enc^T fragments (rows = feature r, K = points in accumulator order)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t qq = q0 + 16 * s2 + 8 * (i >> 2) + 4 * h + (i & 3);
-        const int64_t qqc = qq < n ? qq : n - 1;
-        const float v = in[qqc * ps + (int64_t)(r >> 1) * ls + (r & 1)];
-        nx_t[s2][i] = qq < n ? v : 0.f;
-      }
   };
   if (wave_id < n_tiles) load_raw(wave_id);
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
-    const int64_t p0 = t * 32, p = p0 + r;
+    const int64_t p = t * 32 + r;
     const bool valid = p < n;
-    // ---- operands of this tile
-    Frag3 eb[2], et[2], dt[2];
+    float eb[16];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      eb[ks] = split3(nx_e[ks]);
-      et[ks] = split3(nx_t[ks]);
-    }
+    for (int s = 0; s < 16; ++s) eb[s] = nx[s];
     const float2 d = nx_d;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier readers of dos (previous tile) are done
-    if (h == 0) *reinterpret_cast<float2*>(dos + 2 * r) = d;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // dos visible to the whole wave
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float x[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int q = 16 * s + 8 * (i >> 2) + 4 * h + (i & 3);
-        x[i] = r < 2 ? dos[2 * q + r] : 0.f;
-      }
-      dt[s] = split3(x);
-    }
     if (t + n_waves < n_tiles) load_raw(t + n_waves);
+    // ---- stage dout and the enc tile (rows = feature k = 2s + h, cols = point) in LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier readers (previous tile) are done
+    if (h == 0) *reinterpret_cast<float2*>(dos + 2 * r) = d;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) te[(2 * s + h) * TLD + r] = eb[s];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // A fragments in accumulator-k order: et[g] = enc[point drow(g,h)][feature r], dt[g] = dout[point drow(g,h)][r]
+    float et[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 q4 = *reinterpret_cast<const float4*>(te + r * TLD + 8 * a + 4 * h);
+      et[4 * a] = q4.x;
+      et[4 * a + 1] = q4.y;
+      et[4 * a + 2] = q4.z;
+      et[4 * a + 3] = q4.w;
+    }
     f32x16 denc = {0.f};
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
-      const Frag3 a0 = lds_load_frag(aw, jt * 2, lane), a1 = lds_load_frag(aw, jt * 2 + 1, lane);
       // ---- layout 1: rows = hidden, col = point
-      f32x16 pre = {0.f};
-      mfma6(pre, a0, eb[0]);
-      mfma6(pre, a1, eb[1]);
-      float dp[16], hv1[16];
+      const f32x16 pre = pre_tile(aw, jt, lane, eb);
+      float dp[16], hv[16];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const float4 wa = *reinterpret_cast<const float4*>(w2s + jt * 32 + 8 * a + 4 * h);
@@ -301,54 +236,44 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
         const float was[4] = {wa.x, wa.y, wa.z, wa.w}, wbs[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const float pv = pre[4 * a + b];
-          const float hv = act_f<ACT>(pv);
-          hv1[4 * a + b] = hv;
-          dp[4 * a + b] = fmaf(was[b], d.x, wbs[b] * d.y) * act_d<ACT>(pv, hv);
+          const float hh = act_f<ACT>(pre[4 * a + b]);
+          hv[4 * a + b] = hh;
+          dp[4 * a + b] = fmaf(was[b], d.x, wbs[b] * d.y) * act_d<ACT>(hh);
         }
       }
+      // d enc^T[k][p] += sum_j W1[j][k] dpre[j][p]
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = dp[8 * s + i];
-        mfma6(denc, lds_load_frag(awt, jt * 2 + s, lane), split3(x));
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 a = awt[(jt * 4 + g4) * 64 + lane];
+        denc = mfma32(a.x, dp[4 * g4], denc);
+        denc = mfma32(a.y, dp[4 * g4 + 1], denc);
+        denc = mfma32(a.z, dp[4 * g4 + 2], denc);
+        denc = mfma32(a.w, dp[4 * g4 + 3], denc);
       }
-      // ---- layout 2: rows = point, col = hidden.  h' is the transpose of h: it goes through a
-      // per-wave LDS tile (16 ds_write_b32 + 4 ds_read_b128, both conflict-free with a 36-float
-      // row) instead of being recomputed (12 MFMAs + 16 activations; tanh alone was 37 % of the
-      // kernel's VALU instructions).  act' depends on h only (relu: h > 0; tanh: 1 - h^2).
+      // ---- layout 2: h' = transpose(h) through the per-wave LDS tile
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous readers of the tile are done
 #pragma unroll
-      for (int g = 0; g < 16; ++g) tr[drow(g, h) * 36 + r] = hv1[g];
+      for (int g = 0; g < 16; ++g) tr[drow(g, h) * TLD + r] = hv[g];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const float w20 = w2s[jt * 32 + r], w21 = w2s[HID + jt * 32 + r];
       float hp[16];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const float4 q4 = *reinterpret_cast<const float4*>(tr + r * 36 + 8 * a + 4 * h);
+        const float4 q4 = *reinterpret_cast<const float4*>(tr + r * TLD + 8 * a + 4 * h);
         hp[4 * a] = q4.x;
         hp[4 * a + 1] = q4.y;
         hp[4 * a + 2] = q4.z;
         hp[4 * a + 3] = q4.w;
       }
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float2 dq = *reinterpret_cast<const float2*>(dos + 2 * drow(g, h));
-        const float hv = hp[g];
-        const float dact = ACT == IMMOCO_ACT_RELU ? (hv > 0.f ? 1.f : 0.f) : 1.f - hv * hv;
-        dp[g] = fmaf(w20, dq.x, w21 * dq.y) * dact;
-      }
       f32x16 tmp = {0.f};
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = dp[8 * s + i];
-        mfma6(dw1t[jt], et[s], split3(x));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = hp[8 * s + i];
-        mfma6(tmp, dt[s], split3(x));
+      for (int g = 0; g < 16; ++g) {
+        // dout of row point drow(g,h): re-read from LDS (broadcast) instead of holding 48 registers
+        const float2 dq = *reinterpret_cast<const float2*>(dos + 2 * drow(g, h));
+        const float dpt = fmaf(w20, dq.x, w21 * dq.y) * act_d<ACT>(hp[g]);
+        const float dtg = r == 0 ? dq.x : (r == 1 ? dq.y : 0.f);
+        dw1t[jt] = mfma32(et[g], dpt, dw1t[jt]);  // dW1^T[k][j] += sum_p enc[p][k] dpre'[p][j]
+        tmp = mfma32(dtg, hp[g], tmp);            // dW2^T[o][j] += sum_p dout[p][o] h'[p][j]
       }
       dw2a[jt][0] += tmp[0];  // row o = 0 (lanes h = 0)
       dw2a[jt][1] += tmp[1];  // row o = 1
@@ -371,12 +296,12 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
   for (int jt = 0; jt < NJT; ++jt) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int g = 0; g < 16; ++g) tr[r * 33 + drow(g, h)] = dw1t[jt][g];  // [hidden r][feature k]
+    for (int g = 0; g < 16; ++g) tr[r * TLD + drow(g, h)] = dw1t[jt][g];  // [hidden r][feature k]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int idx = it * 64 + lane;  // (hidden = idx>>5, feature = idx&31) of this 32x32 tile
-      unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, tr[(idx >> 5) * 33 + (idx & 31)]);
+      unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, tr[(idx >> 5) * TLD + (idx & 31)]);
     }
     if (h == 0) {
       unsafeAtomicAdd(dw2 + jt * 32 + r, dw2a[jt][0]);
@@ -385,9 +310,9 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
   }
 }
 
-static size_t fwd_smem(int hid) { return (size_t)(hid / 32) * 2 * 3 * 64 * 16 + (size_t)2 * hid * 4; }
+static size_t fwd_smem(int hid) { return (size_t)(hid / 32) * 4 * 64 * 16 + (size_t)2 * hid * 4; }
 static size_t bwd_smem(int hid) {
-  return (size_t)(hid / 32) * 2 * 3 * 64 * 16 * 2 + (size_t)2 * hid * 4 + 4 * 64 * 4 + (size_t)4 * 32 * 36 * 4;
+  return (size_t)(hid / 32) * 4 * 64 * 16 * 2 + (size_t)2 * hid * 4 + 4 * 64 * 4 + (size_t)4 * 2 * 32 * TLD * 4;
 }
 
 int launch_mlp_fwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
@@ -395,7 +320,9 @@ int launch_mlp_fwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   const int64_t n_tiles = cdiv(n, 32);
-  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_tiles, 4), 2048);
+  // persistent grid (2 workgroups per CU): the per-workgroup weight-fragment build is amortised
+  // over ~16 tiles per wave instead of ~4
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_tiles, 4), 512);
   const size_t sm = fwd_smem(cfg.n_hidden);
 #define IMMOCO_FWD(H, A) mlp_fwd_mfma_kernel<H, A><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, out, n_tiles)
   if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH) IMMOCO_FWD(64, IMMOCO_ACT_TANH);
@@ -411,7 +338,6 @@ template <int HID, int ACT>
 static int launch_bwd_t(const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1, const float* w2,
                         const float* dout, float* din, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane) {
   const int64_t n_tiles = cdiv(n, 32);
-  // HID = 256 keeps 8 accumulator tiles per wave: one wave per SIMD (512-register budget)
   const int blocks_per_cu = HID == 64 ? 2 : 1;
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_tiles, 4), 256 * blocks_per_cu);
   const size_t sm = bwd_smem(HID);
@@ -433,7 +359,8 @@ int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH)
     return launch_bwd_t<64, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
-  if (cfg.n_hidden == 64) return launch_bwd_t<64, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
+  if (cfg.n_hidden == 64)
+    return launch_bwd_t<64, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
   if (cfg.activation == IMMOCO_ACT_TANH)
     return launch_bwd_t<256, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
   return launch_bwd_t<256, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
