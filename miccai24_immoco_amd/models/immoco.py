@@ -243,11 +243,11 @@ class _SolverHandle:
 _SOLVERS = {}
 
 
-def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0) -> _SolverHandle:
+def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, instance=0) -> _SolverHandle:
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts))
+    key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance))
     s = _SOLVERS.get(key)
     if s is None:
         s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts)
@@ -274,7 +274,7 @@ def lambda_schedule(iters, lambda_ge, rule="immoco"):
 
 def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2, debug=False,
                              *, seed=1337, norm_scale=16000.0, lambda_rule="immoco", return_loss=False,
-                             use_graph=True, atomic_scatter=False, grad_parts=0):
+                             use_graph=True, atomic_scatter=False, grad_parts=0, instance=0):
     """IM-MoCo per-slice solve (immoco.py:116-206).
 
     Args mirror the reference: ``kspace_corr`` [H, W] complex (any device), ``masks`` [nM, H, W]
@@ -282,12 +282,15 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
     Returns ``(image_prior, kspace_foward_model)`` of the LAST forward pass, i.e. before the final
     Adam step (immoco.py:203-206).  Keyword-only extras expose the downstream script's variants
     (``norm_scale=8000``, ``lambda_rule="downstream"``; test_immoco_downstream.py:150-152,188-189).
+    The call returns as soon as the work is queued on the solver's own stream (the outputs are
+    ordered after it on the caller's stream); ``instance`` selects one of several solver handles of
+    the same shape, so that independent slices can be in flight concurrently on one GPU.
     """
     L.require_gpu(masks, what="imcoco_motion_correction(masks)")
     dev = masks.device
     nM, H, W = masks.shape
     lambdas = lambda_schedule(iters, lambda_ge, lambda_rule)   # raises ZeroDivisionError like the reference
-    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts)
+    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts, instance)
     k = kspace_corr.to(dev).to(torch.complex64).contiguous()
     if k.shape != (H, W):
         raise L.ImmocoError(f"kspace_corr shape {tuple(k.shape)} does not match masks {(H, W)}")
