@@ -447,8 +447,9 @@ def lambda_schedule(iters: int, lambda_ge: float) -> List[float]:
 
 def oracle_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2,
                              seed=1337, model: Optional[OracleIMMoCo] = None, loss_hist: Optional[list] = None,
-                             norm_scale: float = 16000.0):
-    """src/models/immoco.py:116-206 on the CPU (no .cuda())."""
+                             norm_scale: float = 16000.0, lambda_rule: str = "immoco"):
+    """src/models/immoco.py:116-206 on the CPU (no .cuda()).  norm_scale=8000 and
+    lambda_rule="downstream" give the variant copy of src/test/test_immoco_downstream.py:150-152,188-189."""
     model = model or OracleIMMoCo(masks, seed=seed)
     scale = kspace_corr.abs().max()
     kspace_input = kspace_corr.div(scale).mul(norm_scale).clone().detach()
@@ -465,8 +466,12 @@ def oracle_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
         opt.step()
         if loss_hist is not None:
             loss_hist.append(float(loss.item()))
-        if j % (iters // 10) and j > (iters // 2):
-            lambda_ge *= 0.5
+        if lambda_rule == "immoco":
+            if j % (iters // 10) and j > (iters // 2):
+                lambda_ge *= 0.5
+        else:  # test_immoco_downstream.py:188-189
+            if j % 10 == 0 and j > 80:
+                lambda_ge *= 0.5
     return image_prior, kfm
 
 

@@ -655,3 +655,26 @@ def test_motion_simulation_gpu_vs_reference_golden(env, golden, tag):
     assert np.array_equal(rot.numpy(), g[f"{tag}_rot"]) and np.array_equal(tr.numpy(), g[f"{tag}_tr"])
     s = np.abs(g[f"{tag}_ksp"]).max()
     np.testing.assert_allclose(ksp.cpu().numpy(), g[f"{tag}_ksp"], rtol=1e-3, atol=2e-5 * s)
+
+
+def test_downstream_variant_options_vs_oracle(env, golden, capsys):
+    """Keyword-only variants of the downstream script copy (scale 8000, lambda halved every 10 iterations
+    after 80; src/test/test_immoco_downstream.py:150-152,188-189) and the debug printout."""
+    pkg, L, orc = env
+    g, H, masks = _golden_case(golden, "c32")
+    ksp = torch.from_numpy(g["c32_ksp"])
+    hist = []
+    ref = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config),
+                           motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config))
+    orc.oracle_motion_correction(ksp, masks, iters=95, model=ref, loss_hist=hist, norm_scale=8000.0,
+                                 lambda_rule="downstream")
+    img, kfm, loss = pkg.imcoco_motion_correction(ksp.cuda(), masks.cuda(), iters=95, return_loss=True,
+                                                  norm_scale=8000.0, lambda_rule="downstream", debug=True)
+    out = capsys.readouterr().out
+    assert "Scale:" in out and "iter: 80" in out
+    lh = loss.cpu().numpy()
+    np.testing.assert_allclose(lh[:5], np.array(hist[:5]), rtol=2e-5)
+    # iteration 91 uses lambda/2 (halved at j = 90): the jump in the loss must be there in both
+    assert abs(lh[0] - hist[0]) <= 1e-5 * hist[0]
+    assert lh[91] < lh[89] and hist[91] < hist[89]
+    np.testing.assert_allclose(lh[85:], np.array(hist[85:]), rtol=0.5)
