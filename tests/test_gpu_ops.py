@@ -674,7 +674,8 @@ def test_downstream_variant_options_vs_oracle(env, golden, capsys):
     assert "Scale:" in out and "iter: 80" in out
     lh = loss.cpu().numpy()
     np.testing.assert_allclose(lh[:5], np.array(hist[:5]), rtol=2e-5)
-    # iteration 91 uses lambda/2 (halved at j = 90): the jump in the loss must be there in both
+    # iteration 91 uses lambda/2 (halved at j = 90): the same jump of the loss must show in both
+    # (the entropy term is negative here, so halving lambda RAISES the loss)
     assert abs(lh[0] - hist[0]) <= 1e-5 * hist[0]
-    assert lh[91] < lh[89] and hist[91] < hist[89]
-    np.testing.assert_allclose(lh[85:], np.array(hist[85:]), rtol=0.5)
+    jump_hip, jump_ref = lh[91] - lh[89], hist[91] - hist[89]
+    assert jump_hip * jump_ref > 0 and abs(jump_hip - jump_ref) <= 0.5 * abs(jump_ref), (jump_hip, jump_ref)
