@@ -133,6 +133,16 @@ int immoco_affine_warp_border(const float* image, const float* theta, const floa
 int immoco_band_replace(const float* k0, const float* kall, const int32_t* w0, const int32_t* w1,
                         int32_t n, int32_t H, int32_t W, float* kout, int64_t* mask, void* stream);
 
+/* ---- Autofocusing baseline (src/models/autofocusing.py:71-85): F.affine_grid(align_corners=True) +
+ * F.grid_sample(mode="bicubic", zeros, align_corners=False) of n per-group complex images
+ * [n,H,W] c64 under n affine matrices theta [n][2][3]; out [n,H,W] c64. */
+int immoco_affine_bicubic_fwd(const float* images, const float* theta, const float* xs, const float* ys,
+                              int32_t n, int32_t H, int32_t W, float* out, void* stream);
+/* dtheta [n][2][3] ACCUMULATES the gradient w.r.t. the affine matrices (images are constants). */
+int immoco_affine_bicubic_bwd(const float* images, const float* theta, const float* xs, const float* ys,
+                              const float* dout, int32_t n, int32_t H, int32_t W, float* dtheta,
+                              void* stream);
+
 /* ---- centred FFTs (src/utils/data_utils.py:29-34) over the last two dims.
  * mode 0: FFT  = fftshift(fftn(ifftshift(x)))   unnormalised
  * mode 1: IFFT = ifftshift(ifftn(fftshift(x)))  1/(HW)

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "immoco_warp_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "immoco_affine_warp_border": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "immoco_band_replace": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "immoco_affine_bicubic_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "immoco_affine_bicubic_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "immoco_fft2c": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "immoco_kspace_select": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "immoco_dc_loss": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),

@@ -356,6 +356,107 @@ __global__ __launch_bounds__(256) void band_replace_kernel(const float2* __restr
   if (mask) mask[i] = sel >= 0 ? 1 : 0;
 }
 
+// ---- Autofocusing baseline (reference src/models/autofocusing.py:71-85): per-group affine grid
+// (align_corners=True) + F.grid_sample(mode="bicubic", padding zeros, align_corners=False) of a
+// per-group complex image; backward with respect to the affine matrices only (the images are
+// constants of the method).  ATen cubic convolution, A = -0.75.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  float x = t + 1.f;
+  c[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t;
+  c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t;
+  c[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t;
+  c[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+__device__ __forceinline__ void cubic_coeffs_grad(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  float x = -1.f - t;
+  c[0] = (-3.f * A * x - 10.f * A) * x - 8.f * A;
+  x = -t;
+  c[1] = (-3.f * (A + 2.f) * x - 2.f * (A + 3.f)) * x;
+  x = 1.f - t;
+  c[2] = (3.f * (A + 2.f) * x - 2.f * (A + 3.f)) * x;
+  x = 2.f - t;
+  c[3] = (3.f * A * x - 10.f * A) * x + 8.f * A;
+}
+
+// BWD = false: out[i] = sample ; BWD = true: dtheta[m][6] += d(sum Re(conj(dout) * out))/dtheta
+template <bool BWD>
+__global__ __launch_bounds__(256) void affine_bicubic_kernel(const float2* __restrict__ imgs /*[n][H][W]*/,
+                                                             const float* __restrict__ theta /*[n][2][3]*/,
+                                                             const float* __restrict__ xs,
+                                                             const float* __restrict__ ys, int n, int H, int W,
+                                                             const float2* __restrict__ dout,
+                                                             float2* __restrict__ out, float* __restrict__ dtheta) {
+  const int64_t P = (int64_t)H * W;
+  const int m = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < P) {
+    const int c = (int)(i % W), r = (int)(i / W);
+    const float* t = theta + 6 * m;
+    const float x = xs[c], y = ys[r];
+    const float gx = x * t[0] + y * t[1] + t[2], gy = x * t[3] + y * t[4] + t[5];
+    const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fminf(fmaxf(fx, -4.f), (float)W + 3.f), y0 = (int)fminf(fmaxf(fy, -4.f), (float)H + 3.f);
+    float cx[4], cy[4];
+    cubic_coeffs(ix - fx, cx);
+    cubic_coeffs(iy - fy, cy);
+    const float2* __restrict__ img = imgs + (int64_t)m * P;
+    if (!BWD) {
+      float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float2 v = ld_or_zero(img, y0 - 1 + b, x0 - 1 + a, H, W);
+          const float w = cx[a] * cy[b];
+          acc.x += v.x * w;
+          acc.y += v.y * w;
+        }
+      out[(int64_t)m * P + i] = acc;
+    } else {
+      float dx[4], dy[4];
+      cubic_coeffs_grad(ix - fx, dx);
+      cubic_coeffs_grad(iy - fy, dy);
+      const float2 go = dout[(int64_t)m * P + i];
+      float gix = 0.f, giy = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float2 v = ld_or_zero(img, y0 - 1 + b, x0 - 1 + a, H, W);
+          const float vg = v.x * go.x + v.y * go.y;   // summed over the (re, im) channels
+          gix -= vg * dx[a] * cy[b];
+          giy -= vg * dy[b] * cx[a];
+        }
+      const float ggx = gix * 0.5f * (float)W, ggy = giy * 0.5f * (float)H;
+      g6[0] = ggx * x;
+      g6[1] = ggx * y;
+      g6[2] = ggx;
+      g6[3] = ggy * x;
+      g6[4] = ggy * y;
+      g6[5] = ggy;
+    }
+  }
+  if (BWD) {
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float v = wave_sum(g6[k]);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+      unsafeAtomicAdd(dtheta + 6 * m + threadIdx.x,
+                      red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st) {
   const int64_t n = (int64_t)nM * H * W;
   if (n == 0) return IMMOCO_OK;
@@ -450,6 +551,31 @@ extern "C" int immoco_band_replace(const float* k0, const float* kall, const int
   IMMOCO_REQUIRE(n == 0 || (kall && w0 && w1), "band_replace: NULL buffer");
   band_replace_kernel<<<(unsigned)cdiv((int64_t)H * W, 256), 256, 0, as_stream(stream)>>>(
       (const float2*)k0, (const float2*)kall, w0, w1, n, H, W, (float2*)kout, mask);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+extern "C" int immoco_affine_bicubic_fwd(const float* images, const float* theta, const float* xs, const float* ys,
+                                         int32_t n, int32_t H, int32_t W, float* out, void* stream) {
+  IMMOCO_REQUIRE(n >= 0 && H > 0 && W > 0, "affine_bicubic_fwd: bad shape n=%d H=%d W=%d", n, H, W);
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(images && theta && xs && ys && out, "affine_bicubic_fwd: NULL buffer");
+  dim3 grid((unsigned)cdiv((int64_t)H * W, 256), n);
+  affine_bicubic_kernel<false><<<grid, 256, 0, as_stream(stream)>>>((const float2*)images, theta, xs, ys, n, H, W,
+                                                                   nullptr, (float2*)out, nullptr);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+extern "C" int immoco_affine_bicubic_bwd(const float* images, const float* theta, const float* xs, const float* ys,
+                                         const float* dout, int32_t n, int32_t H, int32_t W, float* dtheta,
+                                         void* stream) {
+  IMMOCO_REQUIRE(n >= 0 && H > 0 && W > 0, "affine_bicubic_bwd: bad shape n=%d H=%d W=%d", n, H, W);
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(images && theta && xs && ys && dout && dtheta, "affine_bicubic_bwd: NULL buffer");
+  dim3 grid((unsigned)cdiv((int64_t)H * W, 256), n);
+  affine_bicubic_kernel<true><<<grid, 256, 0, as_stream(stream)>>>((const float2*)images, theta, xs, ys, n, H, W,
+                                                                  (const float2*)dout, nullptr, dtheta);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch's CPU kernels regress badly with hundreds of threads (the GPU box has 256): the oracle
+    # runs 10x faster with a moderate count
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

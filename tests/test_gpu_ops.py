@@ -679,3 +679,43 @@ def test_downstream_variant_options_vs_oracle(env, golden, capsys):
     assert abs(lh[0] - hist[0]) <= 1e-5 * hist[0]
     jump_hip, jump_ref = lh[91] - lh[89], hist[91] - hist[89]
     assert jump_hip * jump_ref > 0 and abs(jump_hip - jump_ref) <= 0.5 * abs(jump_ref), (jump_hip, jump_ref)
+
+
+# ------------------------------------------------ Autofocusing baseline
+@pytest.mark.parametrize("tag", ["a32", "a48"])
+def test_autofocusing_vs_reference_golden(env, golden, tag):
+    """Forward, loss, parameter gradients and a 12-step Adam loop of the REFERENCE's Autofocusing
+    (pure torch there, so these vectors pin everything incl. the bicubic warp)."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.autofocusing import Autofocusing
+    g = golden("autofocus")
+    ksp = torch.from_numpy(g[f"{tag}_ksp"]).cuda()
+    H = ksp.shape[0]
+    masks = expand_masks(g[f"{tag}_masks_row0"], H).cuda()
+    model = Autofocusing(masks)
+    with torch.no_grad():
+        for n in ("rot_vector", "x_shifts", "y_shifts"):
+            model.motion_parameters[n].copy_(torch.from_numpy(g[f"{tag}_p_{n}"]).cuda())
+    kout = model(ksp)
+    loss = pkg.GradientEntropyLoss()(pkg.IFFT(kout)) * 1e-4
+    loss.backward()
+    sk = np.abs(g[f"{tag}_kout"]).max()
+    np.testing.assert_allclose(kout.detach().cpu().numpy(), g[f"{tag}_kout"], rtol=1e-3, atol=2e-5 * sk)
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) <= 1e-4 * abs(float(g[f"{tag}_loss"]))
+    for n in ("rot_vector", "x_shifts", "y_shifts"):
+        ref = g[f"{tag}_g_{n}"]
+        got = model.motion_parameters[n].grad.cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max() + 1e-9)
+    # optimisation loop of test_autofocusing.py:66-74
+    model = Autofocusing(masks)
+    opt = torch.optim.Adam(model.parameters(), lr=1.0)
+    hist = []
+    for i in range(12):
+        opt.zero_grad()
+        kr = model(ksp)
+        l = pkg.GradientEntropyLoss()(pkg.IFFT(kr)) * 1e-4
+        l.backward()
+        opt.step()
+        hist.append(l.item())
+    np.testing.assert_allclose(np.array(hist[:3]), g[f"{tag}_loop_loss"][:3], rtol=1e-3)
+    np.testing.assert_allclose(np.array(hist), g[f"{tag}_loop_loss"], rtol=5e-2)

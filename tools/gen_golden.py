@@ -167,6 +167,49 @@ def main():
         sol[f"{tag}_kfm"] = kfm.detach().numpy()
         print(tag, "done; |image| max", float(image_prior.abs().max()))
     np.savez_compressed(os.path.join(OUT, "solver.npz"), **sol)
+    # ---------------- E. Autofocusing baseline (src/models/autofocusing.py, loop of
+    # src/test/test_autofocusing.py:66-74) - pure torch in the reference, fully pinned ----------
+    from models import autofocusing as ref_af      # reference
+    af = {}
+    for tag, (H, nm, seed) in {"a32": (32, 2, 13), "a48": (48, 3, 17)}.items():
+        img = phantom(H, H, seed)
+        torch.manual_seed(seed)
+        ksp, mask, _, _ = ref_mu.motion_simulation2D(img.clone(), n_movements=nm)
+        masks = ref_mu.extract_movement_groups(mask.sum(0).div(H) > 0.2, make_list=True)
+        scale = ref_du.IFFT(ksp).abs().max()
+        ksp = ksp / scale
+        model = ref_af.Autofocusing(masks)
+        nM = masks.shape[0]
+        with torch.no_grad():
+            model.motion_parameters["rot_vector"].copy_(torch.linspace(-3.0, 4.0, nM))
+            model.motion_parameters["x_shifts"].copy_(torch.linspace(2.0, -5.0, nM))
+            model.motion_parameters["y_shifts"].copy_(torch.linspace(-1.5, 3.5, nM))
+        kout = model(ksp)
+        loss = ref_losses.GradientEntropyLoss()(ref_du.IFFT(kout)) * 1e-4
+        loss.backward()
+        af[f"{tag}_ksp"] = ksp.numpy()
+        af[f"{tag}_masks_row0"] = masks[:, 0, :].numpy().astype(np.uint8)
+        af[f"{tag}_kout"] = kout.detach().numpy()
+        af[f"{tag}_loss"] = np.float32(loss.item())
+        for nme in ("rot_vector", "x_shifts", "y_shifts"):
+            af[f"{tag}_p_{nme}"] = model.motion_parameters[nme].detach().numpy().copy()
+            af[f"{tag}_g_{nme}"] = model.motion_parameters[nme].grad.numpy().copy()
+        # the optimisation loop of test_autofocusing.py:66-74 from zero parameters
+        model = ref_af.Autofocusing(masks)
+        opt = torch.optim.Adam(model.parameters(), lr=1.0)
+        hist = []
+        for i in range(12):
+            opt.zero_grad()
+            kr = model(ksp)
+            l = ref_losses.GradientEntropyLoss()(ref_du.IFFT(kr)) * 1e-4
+            l.backward()
+            opt.step()
+            hist.append(l.item())
+        af[f"{tag}_loop_loss"] = np.array(hist, dtype=np.float32)
+        af[f"{tag}_loop_kout"] = kr.detach().numpy()
+        for nme in ("rot_vector", "x_shifts", "y_shifts"):
+            af[f"{tag}_loop_{nme}"] = model.motion_parameters[nme].detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "autofocus.npz"), **af)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
