@@ -36,13 +36,23 @@ def extract_movement_groups(motionline_indcies, make_list=False):
         return out
 
 
-def masks_to_col_group(masks: torch.Tensor) -> torch.Tensor:
-    """[nM, H, W] one-hot column masks -> [W] int32 group index (0 = uncorrupted)."""
+def masks_to_col_group(masks: torch.Tensor, validate: bool = True) -> torch.Tensor:
+    """[nM, H, W] one-hot column masks -> [W] int32 group index (0 = uncorrupted).
+
+    The kernels select k-space LINES (reference immoco.py:109-111 multiplies by masks that
+    extract_movement_groups builds constant down every column and disjoint between groups,
+    motion_utils.py:74-107).  `validate` checks exactly that and refuses anything else instead of
+    silently computing a different operator."""
     L.require_gpu(masks, what="masks_to_col_group")
     if masks.dim() != 3:
         raise L.ImmocoError("masks must be [nM, H, W]")
     m = masks.to(torch.long).contiguous()
     nM, H, W = m.shape
+    if validate and nM > 0:
+        ok = bool(((m == m[:, :1, :]).all() & (m[:, 0, :].sum(0) <= 1).all() & ((m == 0) | (m == 1)).all()).item())
+        if not ok:
+            raise L.ImmocoError("masks must be 0/1, constant down each column and disjoint between groups "
+                                "(the output format of extract_movement_groups(..., make_list=True))")
     cg = torch.empty(W, device=m.device, dtype=torch.int32)
     with torch.cuda.device(m.device):
         L.check(L.lib().immoco_masks_to_groups(L.ptr(m), nM, H, W, L.ptr(cg), L.stream_ptr()), "masks_to_groups")

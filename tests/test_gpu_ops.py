@@ -299,6 +299,23 @@ def test_extract_movement_groups_bit_exact(env, golden, tag):
     assert np.array_equal(masks_to_col_group(ml).cpu().numpy(), g[f"{tag}_groups"])
 
 
+def test_masks_that_are_not_line_masks_are_refused(env):
+    pkg, L, orc = env
+    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    m = torch.zeros(2, 8, 8, dtype=torch.long, device="cuda")
+    m[0, :, 2] = 1
+    m[1, :, 5] = 1
+    assert masks_to_col_group(m).tolist() == [0, 0, 1, 0, 0, 2, 0, 0]
+    bad = m.clone()
+    bad[0, 3, 2] = 0                      # not constant down the column
+    with pytest.raises(L.ImmocoError):
+        masks_to_col_group(bad)
+    bad = m.clone()
+    bad[1, :, 2] = 1                      # two groups claim one line
+    with pytest.raises(L.ImmocoError):
+        masks_to_col_group(bad)
+
+
 def test_extract_movement_groups_empty(env):
     pkg, L, orc = env
     ml = pkg.extract_movement_groups(torch.zeros(8, dtype=torch.bool, device="cuda"), make_list=True)
