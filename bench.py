@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-parts", type=int, default=0, help="transposed-index parts (0 = library default)")
+    ap.add_argument("--table-fp16", action="store_true",
+                    help="fp16 hash-grid features (BASELINE config 5 precision); default fp32 like config 2")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -129,11 +131,12 @@ def main():
         masks = pkg.extract_movement_groups(s["lines"], make_list=True)
         slices.append({"kspace": s["kspace"], "masks": masks, "gt": s["gt"].cpu()})
     nM = int(slices[0]["masks"].shape[0])
-    get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts)      # plans + workspace (one-off, like FFT plan creation)
+    get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16)      # plans + workspace (one-off, like FFT plan creation)
 
     def solve(sl):
         return pkg.imcoco_motion_correction(sl["kspace"], sl["masks"], iters=args.iters, learning_rate=1e-2,
-                                            lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts)
+                                            lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts,
+                                            table_fp16=args.table_fp16)
 
     def barrier():
         if dist.is_initialized():
@@ -163,7 +166,7 @@ def main():
         from miccai24_immoco_amd.utils.data_utils import IFFT
         psnr_in = [crop_psnr(IFFT(slices[Wm + j]["kspace"]).abs().cpu(), slices[Wm + j]["gt"].abs()) for j in range(K)]
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
-        solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts)
+        solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16)
         sl = slices[0]
         k = sl["kspace"]
         kin = k / k.abs().max() * 16000
@@ -220,7 +223,7 @@ def main():
             "metric": "slices/sec at 320x320, 10 motion groups, 3000 iters; PSNR delta vs ref",
             "value": round(value, 5), "unit": "slices/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32+f16tab" if args.table_fp16 else "f32", "data": "synthetic",
             "config": {"workload": "C2: single 320x320 slice, 10 motion groups, 3000 Adam iters, hash-grid INRs",
                        "H": H, "W": W, "motion_groups": nM, "iters": args.iters, "slices_per_gpu": K,
                        "graph": bool(solver.graph_active), "parallelism": f"slices sharded over {world} GPU(s)"},

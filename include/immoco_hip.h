@@ -200,7 +200,10 @@ typedef struct immoco_solver_cfg {
                              0 = default 4): each XCD keeps a 8/parts MB slice of dL/denc in its L2 */
   int32_t serial_chains;  /* 1: run the image-INR and motion-INR kernel chains one after the other
                              (default 0: two concurrent branches of the graph) */
-  int32_t reserved[4];
+  int32_t table_fp16;     /* 1: gather the hash-grid features from fp16 shadows of the tables (what
+                             tiny-cuda-nn does; BASELINE config 5), fp32 master tables + fp32 Adam;
+                             default 0: everything fp32 */
+  int32_t reserved[3];
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;

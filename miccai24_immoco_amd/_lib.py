@@ -44,7 +44,8 @@ class SolverCfg(C.Structure):
                 ("image_grid", GridCfg), ("motion_grid", GridCfg),
                 ("image_mlp", MlpCfg), ("motion_mlp", MlpCfg),
                 ("use_graph", C.c_int32), ("atomic_scatter", C.c_int32), ("grad_parts", C.c_int32),
-                ("serial_chains", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("serial_chains", C.c_int32), ("table_fp16", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 _P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32

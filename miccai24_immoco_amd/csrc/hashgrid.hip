@@ -7,6 +7,8 @@
 // stay resident in every XCD's 4 MB L2.  Coordinates either come from a generic
 // [n, D] array (op-level API) or from per-axis lattices (solver: the reference
 // always samples linspace(-1,1,.) lattices, immoco.py:48-53,72-80).
+#include <hip/hip_fp16.h>
+
 #include "kernels.hpp"
 
 namespace immoco {
@@ -68,10 +70,15 @@ __device__ __forceinline__ void load_coords(const float* __restrict__ coords, co
   }
 }
 
-template <int D, bool LAT>
+// TAB = float2: fp32 table; TAB = __half2: fp16 shadow of the table ("fp16 hash-grid features",
+// BASELINE config 5 / what tiny-cuda-nn itself gathers); interpolation is accumulated in fp32 either way.
+__device__ __forceinline__ float2 tab_to_f2(float2 v) { return v; }
+__device__ __forceinline__ float2 tab_to_f2(__half2 v) { return __half22float2(v); }
+
+template <int D, bool LAT, typename TAB = float2>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const float* __restrict__ coords,
                                                            Lattice lat, int64_t n,
-                                                           const float2* __restrict__ table,
+                                                           const TAB* __restrict__ table,
                                                            float* __restrict__ enc, int64_t ps, int64_t ls) {
   const int l = blockIdx.y;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
   const float scale = lv.scale[l];
   const uint32_t size = lv.size[l], res = lv.res[l];
   const bool hashed = (lv.hashed >> l) & 1u, pow2 = (lv.pow2 >> l) & 1u;
-  const float2* __restrict__ tab = table + lv.offset[l];
+  const TAB* __restrict__ tab = table + lv.offset[l];
   uint32_t cell[D];
   float fr[D];
 #pragma unroll
@@ -113,13 +120,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
       wgt[corner] = w;
     }
     if (D == 3 && (idx[0] ^ idx[1]) == 1u) {
-      const float4 q = *reinterpret_cast<const float4*>(tab + (idx[0] & ~1u));
-      const float2 lo = make_float2(q.x, q.y), hi = make_float2(q.z, q.w);
+      struct alignas(2 * sizeof(TAB)) Pair { TAB lo, hi; };
+      const Pair q = *reinterpret_cast<const Pair*>(tab + (idx[0] & ~1u));
+      const float2 lo = tab_to_f2(q.lo), hi = tab_to_f2(q.hi);
       v[2 * pair] = (idx[0] & 1u) ? hi : lo;
       v[2 * pair + 1] = (idx[0] & 1u) ? lo : hi;
     } else {
-      v[2 * pair] = tab[idx[0]];
-      v[2 * pair + 1] = tab[idx[1]];
+      v[2 * pair] = tab_to_f2(tab[idx[0]]);
+      v[2 * pair + 1] = tab_to_f2(tab[idx[1]]);
     }
   }
   float a0 = 0.f, a1 = 0.f;
@@ -185,6 +193,31 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
     if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
     else hashgrid_fwd_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
   }
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+// forward from the fp16 shadow table (lattice mode only: the solver's path)
+int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
+                             int64_t ps, int64_t ls, hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
+  const __half2* t = reinterpret_cast<const __half2*>(table_half2);
+  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
+  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+__global__ __launch_bounds__(256) void f32_to_half_kernel(const float* __restrict__ in, __half* __restrict__ out,
+                                                          int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = __float2half_rn(in[i]);
+}
+
+int launch_f32_to_half(const float* in, void* out_half, int64_t n, hipStream_t st) {
+  if (n == 0) return IMMOCO_OK;
+  f32_to_half_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(in, reinterpret_cast<__half*>(out_half), n);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

@@ -14,6 +14,9 @@ struct Lattice {
 // hashgrid.hip
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
                         const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st);
+int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
+                             int64_t ps, int64_t ls, hipStream_t st);
+int launch_f32_to_half(const float* in, void* out_half, int64_t n, hipStream_t st);
 int launch_hashgrid_bwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
                         const float* denc, int64_t ps, int64_t ls, float* dtable, hipStream_t st);
 int launch_init_uniform(float* out, int64_t n, uint32_t seed, uint32_t stream_id, float lo, float hi,
@@ -71,9 +74,11 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float s
 // device-scheduled variant: scalars read from sched[2*it], it = *iter_dev; g zeroed after use
 // g: n_gparts partial gradient buffers, g_stride floats apart; their sum is the gradient
 // gradients with index >= zero_limit are NOT cleared (their producer overwrites them every iteration)
+// shadow != NULL: the updated parameters with index >= shadow_begin are also written as fp16 to
+// shadow[i - shadow_begin] (fp16 table shadow, fp32 master)
 int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n,
                       int64_t zero_limit, const float* sched, const int32_t* iter_dev, float beta1, float beta2,
-                      float eps, hipStream_t st);
+                      float eps, hipStream_t st, void* shadow = nullptr, int64_t shadow_begin = 0);
 
 // csr.hip — atomic-free hash-grid backward for fixed lattices
 struct CsrPlan;

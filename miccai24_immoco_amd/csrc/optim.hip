@@ -5,6 +5,8 @@
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // HBM-bound: 16-byte loads/stores, grid-stride, 28 B/param (+4 B when the fused
 // zero_grad write is enabled).
+#include <hip/hip_fp16.h>
+
 #include "kernels.hpp"
 
 namespace immoco {
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float step_size, float bc2_sqrt,
                                                    const float* __restrict__ sched,
                                                    const int32_t* __restrict__ iter_dev, float b1, float b2,
-                                                   float eps) {
+                                                   float eps, __half* __restrict__ shadow, int64_t shadow_begin) {
   if (SCHED) {
     const int it = *iter_dev;
     step_size = sched[2 * it];
@@ -49,6 +51,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     adam_one(pp.z, gg.z, mm.z, vv.z, step_size, bc2_sqrt, b1, b2, eps);
     adam_one(pp.w, gg.w, mm.w, vv.w, step_size, bc2_sqrt, b1, b2, eps);
     reinterpret_cast<float4*>(p)[i] = pp;
+    if (shadow && 4 * i >= shadow_begin) {  // shadow_begin is a multiple of 4
+      __half2* sh = reinterpret_cast<__half2*>(shadow + (4 * i - shadow_begin));
+      sh[0] = __floats2half2_rn(pp.x, pp.y);
+      sh[1] = __floats2half2_rn(pp.z, pp.w);
+    }
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
     if (SCHED && 4 * i < zero_limit)  // fused zero_grad (skipped where the producer overwrites)
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float gt = g[t];
     for (int q = 1; q < n_gparts; ++q) gt += g[q * g_stride + t];
     adam_one(p[t], gt, m[t], v[t], step_size, bc2_sqrt, b1, b2, eps);
+    if (shadow && t >= shadow_begin) shadow[t - shadow_begin] = __float2half_rn(p[t]);
     if (SCHED && t < zero_limit)
       for (int q = 0; q < n_gparts; ++q) g[q * g_stride + t] = 0.f;
   }
@@ -73,20 +81,21 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float s
   IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
   adam_kernel<false><<<adam_grid(n), 256, 0, st>>>(p, const_cast<float*>(g), 1, 0, m, v, n, n, step_size, bc2_sqrt,
-                                                   nullptr, nullptr, beta1, beta2, eps);
+                                                   nullptr, nullptr, beta1, beta2, eps, nullptr, 0);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
 
 int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n,
                       int64_t zero_limit, const float* sched, const int32_t* iter_dev, float beta1, float beta2,
-                      float eps, hipStream_t st) {
+                      float eps, hipStream_t st, void* shadow, int64_t shadow_begin) {
+  IMMOCO_REQUIRE(!shadow || (shadow_begin % 4) == 0, "adam: shadow_begin must be a multiple of 4");
   IMMOCO_REQUIRE(n_gparts >= 1 && (g_stride % 4) == 0, "adam: partial gradient stride must be a multiple of 4");
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
   adam_kernel<true><<<adam_grid(n), 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n, zero_limit, 0.f, 1.f, sched, iter_dev, beta1,
-                                                  beta2, eps);
+                                                  beta2, eps, reinterpret_cast<__half*>(shadow), shadow_begin);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

@@ -43,6 +43,7 @@ struct immoco_solver {
   float *fftbuf = nullptr, *dimage = nullptr, *grad_img = nullptr, *grad_mot = nullptr, *kout = nullptr;
   float *sched = nullptr, *lambda_dev = nullptr;
   float *xs = nullptr, *ys = nullptr, *ms = nullptr;  // solver-owned copies of the lattices
+  uint16_t *shadow_img = nullptr, *shadow_mot = nullptr;  // fp16 shadows of the tables (cfg.table_fp16)
   CsrPlan *plan_img = nullptr, *plan_mot = nullptr;
   bool lattice_set = false;
   int mot_parts = 1;            // partial gradient tables of the motion INR
@@ -112,6 +113,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
 
   std::vector<Step> st;
   st.push_back({"image_encode_fwd", [=](hipStream_t q) {
+                  if (s->cfg.table_fp16) return launch_hashgrid_fwd_half(s->lv_img, li, P, s->shadow_img, s->enc_img, 2, 2 * P, q);
                   return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, 2, 2 * P, q);
                 }, 2});
   st.push_back({"image_mlp_fwd", [=](hipStream_t q) {
@@ -120,6 +122,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }, 2});
   if (nM > 0) {
     st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
+                    if (s->cfg.table_fp16)
+                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, 2, 2 * NP, q);
                     return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
                   }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
@@ -171,13 +175,15 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                                    : s->n_params_mot;
                     return launch_adam_sched(b.p_mot, s->grad_mot, s->plan_mot ? s->mot_parts : 1, s->mot_gstride,
                                              b.a_mot, b.a_mot + s->n_params_mot, s->n_params_mot, zl, s->sched,
-                                             s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
+                                             s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
+                                             s->cfg.table_fp16 ? s->shadow_mot : nullptr, s->n_w_mot);
                   }, 1});
   st.push_back({"adam_image", [=](hipStream_t q) {
                   const int64_t zl = s->plan_img ? ((s->n_w_img + 2 * (int64_t)csr_plan_shared_slot_end(s->plan_img) + 3) / 4 * 4)
                                                  : s->n_params_img;
                   return launch_adam_sched(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
-                                           s->n_params_img, zl, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q);
+                                           s->n_params_img, zl, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
+                                           s->cfg.table_fp16 ? s->shadow_img : nullptr, s->n_w_img);
                 }, 2});
   st.push_back({"tick", [=](hipStream_t q) {
                   tick_kernel<<<1, 1, 0, q>>>(s->iter_dev);
@@ -212,6 +218,15 @@ int ensure_sched(immoco_solver* s, int32_t iters) {
     s->gexec = nullptr;
   }
   return IMMOCO_OK;
+}
+
+// fp16 mode: (re)build the shadows from the caller's fp32 master tables
+int refresh_shadows(immoco_solver* s, const float* p_img, const float* p_mot, hipStream_t q) {
+  if (!s->cfg.table_fp16) return IMMOCO_OK;
+  int rc = launch_f32_to_half(p_img + s->n_w_img, s->shadow_img, s->n_params_img - s->n_w_img, q);
+  if (rc == IMMOCO_OK && s->cfg.nM > 0)
+    rc = launch_f32_to_half(p_mot + s->n_w_mot, s->shadow_mot, s->n_params_mot - s->n_w_mot, q);
+  return rc;
 }
 
 int enter(immoco_solver* s, hipStream_t caller) {
@@ -303,6 +318,10 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   s->mot_gstride = (s->n_params_mot + 3) / 4 * 4;
   A(grad_mot, s->mot_gstride * s->mot_parts)
   A(iter_dev, 4)
+  if (cfg->table_fp16) {
+    A(shadow_img, s->n_params_img - s->n_w_img)
+    A(shadow_mot, s->n_params_mot - s->n_w_mot)
+  }
   A(xs, cfg->W)
   A(ys, cfg->H)
   A(ms, cfg->nM > 0 ? cfg->nM : 1)
@@ -341,6 +360,8 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   for (float* b : bufs)
     if (b) hipFree(b);
   if (s->iter_dev) hipFree(s->iter_dev);
+  if (s->shadow_img) hipFree(s->shadow_img);
+  if (s->shadow_mot) hipFree(s->shadow_mot);
   if (s->ev_in) hipEventDestroy(s->ev_in);
   if (s->ev_out) hipEventDestroy(s->ev_out);
   for (hipEvent_t ev : s->ev_fj)
@@ -422,6 +443,7 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   if (loss_hist) IMMOCO_CHECK_HIP(hipMemsetAsync(loss_hist, 0, (size_t)iters * 4, q));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
 
+  if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
   Bind b{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
   std::vector<Step> steps = build_steps(s, b, true);
   s->graph_active = 0;
@@ -473,6 +495,7 @@ extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group
   hipStream_t q = s->stream;
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   // kin only feeds the (unused) residual here: point it at kout itself
+  if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
   Bind b{s->kout, col_group, const_cast<float*>(params_image), const_cast<float*>(params_motion),
          nullptr, nullptr, nullptr};
   std::vector<Step> steps = build_steps(s, b, false);
@@ -504,6 +527,7 @@ extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, 
   IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));
+  if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
   Bind b{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, nullptr};
   std::vector<Step> steps = build_steps(s, b, true);
   const size_t n = steps.size();

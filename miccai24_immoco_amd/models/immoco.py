@@ -146,14 +146,14 @@ class IMMoCo(nn.Module):
 class _SolverHandle:
     """RAII wrapper of immoco_solver_t; cached per (device, H, W, nM)."""
 
-    def __init__(self, device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0):
+    def __init__(self, device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, table_fp16=False):
         self.device, self.H, self.W, self.nM = device, H, W, nM
         self.image_grid = L.grid_cfg(2, encoding_config)
         self.motion_grid = L.grid_cfg(3, encoding_config)
         self.image_mlp = L.mlp_cfg(32, 2, network_config)
         self.motion_mlp = L.mlp_cfg(32, 2, mot_network_config)
         cfg = L.SolverCfg(H, W, nM, self.image_grid, self.motion_grid, self.image_mlp, self.motion_mlp,
-                          1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts))
+                          1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts), 0, 1 if table_fp16 else 0)
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(L.lib().immoco_solver_create(C.byref(cfg), C.byref(self.handle)), "solver_create")
@@ -243,14 +243,16 @@ class _SolverHandle:
 _SOLVERS = {}
 
 
-def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, instance=0) -> _SolverHandle:
+def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, instance=0,
+               table_fp16=False) -> _SolverHandle:
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance))
+    key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance),
+           bool(table_fp16))
     s = _SOLVERS.get(key)
     if s is None:
-        s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts)
+        s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts, table_fp16)
     return s
 
 
@@ -274,7 +276,7 @@ def lambda_schedule(iters, lambda_ge, rule="immoco"):
 
 def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2, debug=False,
                              *, seed=1337, norm_scale=16000.0, lambda_rule="immoco", return_loss=False,
-                             use_graph=True, atomic_scatter=False, grad_parts=0, instance=0):
+                             use_graph=True, atomic_scatter=False, grad_parts=0, instance=0, table_fp16=False):
     """IM-MoCo per-slice solve (immoco.py:116-206).
 
     Args mirror the reference: ``kspace_corr`` [H, W] complex (any device), ``masks`` [nM, H, W]
@@ -284,13 +286,15 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
     (``norm_scale=8000``, ``lambda_rule="downstream"``; test_immoco_downstream.py:150-152,188-189).
     The call returns as soon as the work is queued on the solver's own stream (the outputs are
     ordered after it on the caller's stream); ``instance`` selects one of several solver handles of
-    the same shape, so that independent slices can be in flight concurrently on one GPU.
+    the same shape, so that independent slices can be in flight concurrently on one GPU;
+    ``table_fp16=True`` gathers the hash-grid features from fp16 shadows of the fp32 master tables
+    (tiny-cuda-nn's own precision; BASELINE config 5).
     """
     L.require_gpu(masks, what="imcoco_motion_correction(masks)")
     dev = masks.device
     nM, H, W = masks.shape
     lambdas = lambda_schedule(iters, lambda_ge, lambda_rule)   # raises ZeroDivisionError like the reference
-    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts, instance)
+    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts, instance, table_fp16)
     k = kspace_corr.to(dev).to(torch.complex64).contiguous()
     if k.shape != (H, W):
         raise L.ImmocoError(f"kspace_corr shape {tuple(k.shape)} does not match masks {(H, W)}")

@@ -298,8 +298,9 @@ class OracleINR(torch.nn.Module):
     Parameter like the tcnn torch binding.  The coordinate plan is cached on the
     first forward (the reference always passes the same grid)."""
 
-    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337):
+    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False):
         super().__init__()
+        self.table_fp16 = table_fp16   # gather from an fp16 copy of the table (fp32 master, straight-through)
         self.geo = geometry_from_config(n_input_dims, encoding_config)
         self.mlp = mlp_spec_from_config(self.geo.enc_width, n_output_dims, network_config)
         self.n_output_dims = n_output_dims
@@ -326,6 +327,8 @@ class OracleINR(torch.nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         w1, w2, tab = self.split()
+        if self.table_fp16:
+            tab = tab + (tab.half().float() - tab).detach()
         enc = self.plan_for(x).encode(tab)
         pre = enc @ w1.t()
         h = torch.relu(pre) if self.mlp.activation == "relu" else torch.tanh(pre)
