@@ -11,6 +11,9 @@ from . import _lib  # noqa: F401
 from .models.immoco import (IMMoCo, encoding_config, imcoco_motion_correction, make_grids,  # noqa: F401
                             mot_network_config, network_config)
 from .models.autofocusing import Autofocusing  # noqa: F401
+from .models.kld_net import get_unet  # noqa: F401
+from .pipeline import correct_slice, evaluate_slices  # noqa: F401
+from .utils.evaluate import calmetric2D  # noqa: F401
 from .tcnn import NetworkWithInputEncoding  # noqa: F401
 from .utils.data_utils import FFT, IFFT  # noqa: F401
 from .utils.losses import GradientEntropyLoss  # noqa: F401
