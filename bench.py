@@ -158,6 +158,8 @@ def main():
         dt = float(t.item())
     value = K * world / dt
     ms_per_step = dt / K * 1e3
+    graph_used = bool(get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0,
+                                 args.table_fp16).graph_active)          # of the timed solves
 
     out = None
     if rank == 0:
@@ -207,12 +209,31 @@ def main():
                 traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             except Exception:
                 traffic = None
+        # The same request shape measured bare on this GPU (csrc/probe.hip): the kernel issues one divergent
+        # 8-byte dL/denc gather per (point, corner, level) entry, inside a 2 MB footprint per XCD (one part of
+        # a level slice); the probe issues random aligned 8-byte loads inside 2 MB and nothing else.
+        import ctypes as C
+        from miccai24_immoco_amd import _lib as L
+        probe_ms = C.c_float()
+        L.check(L.lib().immoco_probe_gather(2 << 20, 8, 1024000, 64, 5,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                            C.byref(probe_ms)), "probe_gather")
+        ceiling = 1024000 * 64 / (probe_ms.value * 1e-3) / 1e9
+        n_req = nM * H * W * 16 * 8
+        gather = {"requests_per_launch": n_req, "achieved_Greq_s": round(n_req / (ms * 1e-3) / 1e9, 1),
+                  "achieved_isolated_Greq_s": round(n_req / (dict(phases)[name] * 1e-3) / 1e9, 1),
+                  "ceiling_Greq_s": round(ceiling, 1), "frac": round(n_req / (ms * 1e-3) / 1e9 / ceiling, 4),
+                  "frac_isolated": round(n_req / (dict(phases)[name] * 1e-3) / 1e9 / ceiling, 4),
+                  "ceiling_source": "immoco_probe_gather, measured in this run: random aligned 8-byte loads, "
+                                    "2 MB footprint, 1 024 000 lanes x 64 loads"}
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": round(ms, 4), "kernel_ms_isolated": round(dict(phases)[name], 4),
             "kernel_algorithmic_bytes": ab[name],
-            "note": "gather kernels are bound by the L1 miss-concurrency / TA rate (rocprof: TA busy 94 %), not by HBM bytes",
+            "note": "gather kernels are bound by the rate of divergent cache-line requests (rocprof: TA busy 94 %), "
+                    "not by HBM bytes: see `gather` for the measured ceiling of that request shape",
+            "gather": gather,
             "iteration": {"algorithmic_bytes": b_iter, "ms_graph": round(iter_ms_graph, 4),
                           "ms_sum_of_kernels_eager": round(t_iter_ms, 4),
                           "achieved_GBs": round(b_iter / (iter_ms_graph * 1e-3) / 1e9, 2),
@@ -226,7 +247,7 @@ def main():
             "vs_baseline": None, "dtype": "f32+f16tab" if args.table_fp16 else "f32", "data": "synthetic",
             "config": {"workload": "C2: single 320x320 slice, 10 motion groups, 3000 Adam iters, hash-grid INRs",
                        "H": H, "W": W, "motion_groups": nM, "iters": args.iters, "slices_per_gpu": K,
-                       "graph": bool(solver.graph_active), "parallelism": f"slices sharded over {world} GPU(s)"},
+                       "graph": graph_used, "parallelism": f"slices sharded over {world} GPU(s)"},
             "psnr_db": {"solved": [round(p, 3) for p in psnr], "corrupted_input": [round(p, 3) for p in psnr_in]},
             "roofline": roofline,
         }

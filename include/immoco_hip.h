@@ -259,6 +259,14 @@ int immoco_solver_set_graph(immoco_solver_t s, int32_t use_graph);
 /* 1 when the last solve replayed a captured hipGraph, 0 when it launched eagerly. */
 int immoco_solver_graph_active(immoco_solver_t s);
 
+/* Measurement aid (bench.py `roofline.gather_ceiling`), no counterpart in the reference: the rate the
+ * chip sustains for the request shape of the hash-grid kernels - n_lanes lanes, each issuing
+ * loads_per_lane independent bytes_per_load-byte (8 or 16) loads at pseudo-random aligned offsets of a
+ * footprint_bytes table (power of two), 4 in flight per lane.  Allocates and frees its own scratch.
+ * ms_out: [host] average duration of one launch over `repeats` launches. */
+int immoco_probe_gather(int64_t footprint_bytes, int32_t bytes_per_load, int64_t n_lanes,
+                        int32_t loads_per_lane, int32_t repeats, hipStream_t stream, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

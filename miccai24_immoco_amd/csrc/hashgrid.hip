@@ -75,16 +75,17 @@ __device__ __forceinline__ void load_coords(const float* __restrict__ coords, co
 __device__ __forceinline__ float2 tab_to_f2(float2 v) { return v; }
 __device__ __forceinline__ float2 tab_to_f2(__half2 v) { return __half22float2(v); }
 
-template <int D, bool LAT, typename TAB = float2>
-__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const float* __restrict__ coords,
-                                                           Lattice lat, int64_t n,
-                                                           const TAB* __restrict__ table,
-                                                           float* __restrict__ enc, int64_t ps, int64_t ls) {
-  const int l = blockIdx.y;
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  float x[D];
-  load_coords<D, LAT>(coords, lat, p, x);
+// One (point, level) of the encoding: gathers the 2^D corners and interpolates.
+// The two corners that differ in dimension 0 sit in ONE aligned 16-byte pair of the table whenever
+// their indices differ only in bit 0 (dense levels with an even cell; hashed levels with an even
+// dim-0 cell, because dim 0 carries the prime 1): one dwordx4 load then serves both.  For the motion
+// grid dim 0 is the motion group, constant over a wave, so the choice is wave-uniform: ~27 % fewer
+// divergent loads on the TA-bound gather (rocprof: SQ_WAIT_INST_ANY 72 % of wave cycles before).
+// Measured alternatives: `nt` loads 1.30 ms, `sc1` (L1-bypass) loads 0.49 ms, plain loads 0.43 ms,
+// plain + pair merge 0.36 ms.
+template <int D, typename TAB>
+__device__ __forceinline__ float2 encode_point_level(const Levels& lv, int l, const float (&x)[D],
+                                                     const TAB* __restrict__ table) {
   const float scale = lv.scale[l];
   const uint32_t size = lv.size[l], res = lv.res[l];
   const bool hashed = (lv.hashed >> l) & 1u, pow2 = (lv.pow2 >> l) & 1u;
@@ -93,13 +94,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
   float fr[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) pos_fract(x[d], scale, cell[d], fr[d]);
-  // Gather all corners first.  The two corners that differ in dimension 0 sit in ONE aligned
-  // 16-byte pair of the table whenever their indices differ only in bit 0 (dense levels with an
-  // even cell; hashed levels with an even dim-0 cell, because dim 0 carries the prime 1): one
-  // dwordx4 load then serves both.  For the motion grid dim 0 is the motion group, constant over a
-  // wave, so the choice is wave-uniform: ~27 % fewer divergent loads on the TA-bound gather
-  // (rocprof: SQ_WAIT_INST_ANY 72 % of wave cycles before).  Measured alternatives: `nt` loads
-  // 1.30 ms, `sc1` (L1-bypass) loads 0.49 ms, plain loads 0.43 ms, plain + pair merge 0.36 ms.
   float2 v[1 << D];
   float wgt[1 << D];
 #pragma unroll
@@ -138,8 +132,27 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
     a0 = corner == 0 ? t0 : add_nc(a0, t0);
     a1 = corner == 0 ? t1 : add_nc(a1, t1);
   }
-  *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = make_float2(a0, a1);
+  return make_float2(a0, a1);
 }
+
+template <int D, bool LAT, typename TAB = float2>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const float* __restrict__ coords,
+                                                           Lattice lat, int64_t n,
+                                                           const TAB* __restrict__ table,
+                                                           float* __restrict__ enc, int64_t ps, int64_t ls) {
+  const int l = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  float x[D];
+  load_coords<D, LAT>(coords, lat, p, x);
+  *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = encode_point_level<D, TAB>(lv, l, x, table);
+}
+
+// Measured dead end: a "level sweep" launch (one workgroup keeps 512 points and walks the 16 levels, meant
+// to keep a single 4 MB level slice live per XCD L2) ran at 0.81 ms instead of 0.36 ms: workgroups drift
+// apart and soon touch 3-4 level slices at once, and immoco_probe_gather shows the price - random 16-byte
+// gathers sustain 259 G requests/s inside a 4 MB footprint, 120 G/s inside 8 MB, 80 G/s inside 16 MB.
+// The (points, level) grid below keeps at most two slices live.
 
 // v1 backward: one float atomic per (corner, feature).
 template <int D, bool LAT>
