@@ -302,7 +302,9 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   }
   // XCD-aware interleave: workgroup i runs on XCD i % 8 (observed round-robin dispatch; a different
   // placement only costs speed).  XCD x serves part x % NP; the 8/NP XCDs of a part alternate over
-  // that part's item list.  NP must divide 8.
+  // that part's item list.  NP must divide 8.  (Part-major order - all XCDs on one part at a time, which
+  // would allow pipelining the MLP backward of part k+1 under the encode backward of part k - costs
+  // 0.68 ms instead of 0.59 ms: every XCD then pulls every part's dL/denc slices through its L2.)
   std::vector<BwdItem> items;
   if (NP == 1) {
     items = per_part[0];
