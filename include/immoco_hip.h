@@ -236,6 +236,15 @@ int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t
                         float lr, const float* lambda_sched /*[host]*/, int32_t step0,
                         float* out_image, float* out_kspace, float* loss_hist, void* stream);
 
+/* The same for a batch of B slices of the solver's shape (BASELINE config 3; SURVEY §8b "over a batch
+ * dimension B of slices"): every buffer gains a leading dimension B - kspace_in [B,H,W] c64, col_group
+ * [B,W], params_* [B,n_params], adam_* [B,2*n_params], out_* [B,H,W] c64, loss_hist [B,iters] or NULL;
+ * lambda_sched / lr / step0 are shared.  Slices are solved one after the other on the solver's streams. */
+int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const float* kspace_in, const int32_t* col_group,
+                              float* params_image, float* params_motion, float* adam_image, float* adam_motion,
+                              int32_t iters, float lr, const float* lambda_sched, int32_t step0,
+                              float* out_image, float* out_kspace, float* loss_hist, void* stream);
+
 /* One forward pass only (IMMoCo.forward, immoco.py:82-113). */
 int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* params_image,
                           const float* params_motion, float* out_image, float* out_kspace,

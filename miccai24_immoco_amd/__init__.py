@@ -8,7 +8,8 @@ There is no CPU or PyTorch fallback: every operator raises if the library is
 missing or a tensor is not on the GPU.
 """
 from . import _lib  # noqa: F401
-from .models.immoco import (IMMoCo, encoding_config, imcoco_motion_correction, make_grids,  # noqa: F401
+from .models.immoco import (IMMoCo, encoding_config, imcoco_motion_correction,  # noqa: F401
+                            imcoco_motion_correction_batch, make_grids,
                             mot_network_config, network_config)
 from .models.autofocusing import Autofocusing  # noqa: F401
 from .models.kld_net import get_unet  # noqa: F401

@@ -84,6 +84,8 @@ PROTOTYPES = {
     "immoco_solver_set_lattice": (C.c_int, [_P, _P, _P, _P, _P]),
     "immoco_solver_solve": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _F,
                                       C.POINTER(C.c_float), _I32, _P, _P, _P, _P]),
+    "immoco_solver_solve_batch": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _F,
+                                            C.POINTER(C.c_float), _I32, _P, _P, _P, _P]),
     "immoco_solver_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "immoco_solver_profile": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _F, _F, _P]),
     "immoco_grid_plan_create": (C.c_int, [_GP, _I32, _I32, _I32, _P, _P, _P, C.POINTER(C.c_void_p), _P]),

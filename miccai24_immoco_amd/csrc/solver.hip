@@ -483,6 +483,31 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   return leave(s, caller);
 }
 
+// Batch of B independent slices of one shape (BASELINE config 3): slice after slice on the solver's
+// stream - the gather kernels of one slice already fill the chip, so slices in flight
+// side by side bring no throughput.
+extern "C" int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const float* kspace_in,
+                                         const int32_t* col_group, float* params_image, float* params_motion,
+                                         float* adam_image, float* adam_motion, int32_t iters, float lr,
+                                         const float* lambda_sched, int32_t step0, float* out_image,
+                                         float* out_kspace, float* loss_hist, void* stream) {
+  IMMOCO_REQUIRE(s, "solver_solve_batch: NULL solver");
+  IMMOCO_REQUIRE(B >= 0, "solver_solve_batch: negative batch size %d", B);
+  const int64_t P2 = 2 * s->P, W = s->cfg.W;
+  for (int32_t i = 0; i < B; ++i) {
+    int rc = immoco_solver_solve(
+        s, kspace_in ? kspace_in + i * P2 : nullptr, col_group ? col_group + i * W : nullptr,
+        params_image ? params_image + i * s->n_params_img : nullptr,
+        params_motion ? params_motion + i * s->n_params_mot : nullptr,
+        adam_image ? adam_image + 2 * i * s->n_params_img : nullptr,
+        adam_motion ? adam_motion + 2 * i * s->n_params_mot : nullptr, iters, lr, lambda_sched, step0,
+        out_image ? out_image + i * P2 : nullptr, out_kspace ? out_kspace + i * P2 : nullptr,
+        loss_hist ? loss_hist + (int64_t)i * iters : nullptr, stream);
+    if (rc) return rc;
+  }
+  return IMMOCO_OK;
+}
+
 extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* params_image,
                                      const float* params_motion, float* out_image, float* out_kspace,
                                      void* stream) {

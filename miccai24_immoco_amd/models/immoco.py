@@ -207,6 +207,21 @@ class _SolverHandle:
                 L.ptr(out_img), L.ptr(out_k), L.ptr(loss), L.stream_ptr()), "solver_solve")
         return out_img, out_k, loss
 
+    def solve_batch(self, kspace_norm, col_group, p_img, p_mot, a_img, a_mot, iters, lr, lambdas, step0=0,
+                    want_loss=False):
+        """B slices in one call: every tensor carries a leading batch dimension."""
+        dev, B = self.device, int(kspace_norm.shape[0])
+        out_img = torch.empty((B, self.H, self.W), device=dev, dtype=torch.complex64)
+        out_k = torch.empty((B, self.H, self.W), device=dev, dtype=torch.complex64)
+        loss = torch.empty((B, iters), device=dev, dtype=torch.float32) if want_loss else None
+        lam = (C.c_float * iters)(*[float(v) for v in lambdas])
+        with torch.cuda.device(dev):
+            L.check(L.lib().immoco_solver_solve_batch(
+                self.handle, B, L.ptr(kspace_norm), L.ptr(col_group),
+                L.ptr(p_img), L.ptr(p_mot), L.ptr(a_img), L.ptr(a_mot), iters, float(lr), lam, int(step0),
+                L.ptr(out_img), L.ptr(out_k), L.ptr(loss), L.stream_ptr()), "solver_solve_batch")
+        return out_img, out_k, loss
+
     def forward(self, col_group, p_img, p_mot):
         out_img = torch.empty((self.H, self.W), device=self.device, dtype=torch.complex64)
         out_k = torch.empty((self.H, self.W), device=self.device, dtype=torch.complex64)
@@ -317,3 +332,55 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
     if return_loss:
         return image_prior, kfm, loss
     return image_prior, kfm
+
+
+def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate=1e-2, lambda_ge=1e-2, *, seed=1337,
+                                   norm_scale=16000.0, lambda_rule="immoco", return_loss=False, use_graph=True,
+                                   table_fp16=False):
+    """``imcoco_motion_correction`` for a batch (BASELINE config 3: B slices resident on one GPU):
+    ``kspaces [B, H, W] c64`` and one ``masks [nM_i, H, W]`` per slice.  Slices with the same number of
+    movement groups share one ``immoco_solver_solve_batch`` call (parameters, Adam state and outputs live in
+    ``[B_g, ...]`` tensors; 305 MB of fp32 state per slice).  Returns ``(image_prior [B, H, W],
+    kspace_foward_model [B, H, W])`` (+ ``loss [B, iters]`` with ``return_loss``), slice i initialised like a
+    single call with the same ``seed``."""
+    if kspaces.dim() != 3 or len(masks_list) != kspaces.shape[0]:
+        raise L.ImmocoError("kspaces must be [B, H, W] with one masks tensor per slice")
+    B, H, W = kspaces.shape
+    L.require_gpu(kspaces, *masks_list, what="imcoco_motion_correction_batch")
+    dev = kspaces.device
+    lambdas = lambda_schedule(iters, lambda_ge, lambda_rule)
+    images = torch.empty((B, H, W), device=dev, dtype=torch.complex64)
+    kfms = torch.empty_like(images)
+    losses = torch.empty((B, iters), device=dev, dtype=torch.float32) if return_loss else None
+    by_nm = {}
+    for i, m in enumerate(masks_list):
+        if m.dim() != 3 or tuple(m.shape[1:]) != (H, W):
+            raise L.ImmocoError(f"masks[{i}] shape {tuple(m.shape)} does not match kspaces {(H, W)}")
+        by_nm.setdefault(int(m.shape[0]), []).append(i)
+    for nM, idx in sorted(by_nm.items()):
+        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16)
+        Bg = len(idx)
+        k = kspaces[idx].to(torch.complex64).contiguous()
+        kin = torch.empty_like(k)
+        scale = torch.empty(1, device=dev, dtype=torch.float32)
+        cgs = torch.zeros((Bg, W), device=dev, dtype=torch.int32)
+        p_img = torch.empty((Bg, solver.n_params_image), device=dev, dtype=torch.float32)
+        p_mot = torch.empty((Bg, max(solver.n_params_motion, 1)), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            for j, i in enumerate(idx):
+                L.check(L.lib().immoco_normalize_kspace(L.ptr(k[j]), H * W, float(norm_scale), L.ptr(kin[j]),
+                                                        L.ptr(scale), L.stream_ptr()), "normalize_kspace")
+                if nM > 0:
+                    cgs[j] = masks_to_col_group(masks_list[i].to(dev))
+        pi0, pm0 = solver.init_params(seed, seed)
+        p_img[:] = pi0
+        p_mot = pm0.expand(Bg, -1).contiguous() if nM > 0 else p_mot
+        a_img = torch.zeros((Bg, 2 * solver.n_params_image), device=dev, dtype=torch.float32)
+        a_mot = torch.zeros((Bg, 2 * solver.n_params_motion), device=dev, dtype=torch.float32)
+        im, kf, ls = solver.solve_batch(kin, cgs, p_img, p_mot, a_img, a_mot, iters, learning_rate, lambdas,
+                                        want_loss=return_loss)
+        ii = torch.as_tensor(idx, device=dev)
+        images[ii], kfms[ii] = im, kf
+        if return_loss:
+            losses[ii] = ls
+    return (images, kfms, losses) if return_loss else (images, kfms)

@@ -767,3 +767,26 @@ def test_autofocusing_vs_reference_golden(env, golden, tag):
         hist.append(l.item())
     np.testing.assert_allclose(np.array(hist[:3]), g[f"{tag}_loop_loss"][:3], rtol=1e-3)
     np.testing.assert_allclose(np.array(hist), g[f"{tag}_loop_loss"], rtol=5e-2)
+
+
+def test_batch_solve_matches_single_slices(env):
+    """BASELINE config 3 entry (immoco_solver_solve_batch): a batch with mixed group counts equals the
+    per-slice calls (same seeds) in the first iterations and returns per-slice results in input order."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd import synth
+    sls = [synth.make_slice(64, 64, nm, i, device="cuda") for i, nm in enumerate((3, 2, 3))]
+    masks = [pkg.extract_movement_groups(s["lines"], make_list=True) for s in sls]
+    assert len({int(m.shape[0]) for m in masks}) >= 1
+    ksp = torch.stack([s["kspace"] for s in sls])
+    imgs, kfms, loss = pkg.imcoco_motion_correction_batch(ksp, masks, iters=30, return_loss=True)
+    assert imgs.shape == (3, 64, 64) and kfms.shape == (3, 64, 64) and loss.shape == (3, 30)
+    for i in range(3):
+        im1, kf1, l1 = pkg.imcoco_motion_correction(ksp[i], masks[i], iters=30, return_loss=True)
+        np.testing.assert_allclose(loss[i, :6].cpu().numpy(), l1[:6].cpu().numpy(), rtol=2e-5)
+        np.testing.assert_allclose(loss[i].cpu().numpy(), l1.cpu().numpy(), rtol=0.05)
+        e = float((imgs[i] - im1).abs().norm() / im1.abs().norm())
+        assert e < 0.05, (i, e)
+    with pytest.raises(L.ImmocoError):
+        pkg.imcoco_motion_correction_batch(ksp, masks[:2], iters=30)
+    with pytest.raises(L.ImmocoError):
+        pkg.imcoco_motion_correction_batch(ksp.cpu(), masks, iters=30)
