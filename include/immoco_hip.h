@@ -77,6 +77,12 @@ int immoco_grid_geometry_query(const immoco_grid_cfg* cfg, immoco_grid_geometry*
 int immoco_hashgrid_fwd(const immoco_grid_cfg* cfg, const float* coords /*[n,dims]*/, int64_t n,
                         const float* table, float* enc, int64_t enc_point_stride,
                         int64_t enc_level_stride, void* stream);
+/* The same from an fp16 table ([n_entries][2] half): tiny-cuda-nn's own parameter precision (SURVEY §8b
+ * "fp32 and fp16 tables"); each entry is widened to fp32, then the arithmetic is that of immoco_hashgrid_fwd.
+ * Gradients always go to an fp32 table (immoco_hashgrid_bwd). */
+int immoco_hashgrid_fwd_f16(const immoco_grid_cfg* cfg, const float* coords /*[n,dims]*/, int64_t n,
+                            const void* table_f16, float* enc, int64_t enc_point_stride,
+                            int64_t enc_level_stride, void* stream);
 /* Accumulates dtable[n_entries][2] += scatter(denc) (same strides as fwd). */
 int immoco_hashgrid_bwd(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
                         const float* denc, int64_t enc_point_stride, int64_t enc_level_stride,

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "immoco_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "immoco_grid_geometry_query": (C.c_int, [_GP, C.POINTER(GridGeometry)]),
     "immoco_hashgrid_fwd": (C.c_int, [_GP, _P, _I64, _P, _P, _I64, _I64, _P]),
+    "immoco_hashgrid_fwd_f16": (C.c_int, [_GP, _P, _I64, _P, _P, _I64, _I64, _P]),
     "immoco_hashgrid_bwd": (C.c_int, [_GP, _P, _I64, _P, _I64, _I64, _P, _P]),
     "immoco_mlp_fwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "immoco_mlp_bwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),

@@ -305,6 +305,29 @@ extern "C" int immoco_hashgrid_fwd(const immoco_grid_cfg* cfg, const float* coor
                              as_stream(stream));
 }
 
+extern "C" int immoco_hashgrid_fwd_f16(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
+                                       const void* table_f16, float* enc, int64_t enc_point_stride,
+                                       int64_t enc_level_stride, void* stream) {
+  Levels lv;
+  int rc = build_levels(cfg, &lv);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(n >= 0 && (n == 0 || (coords && table_f16 && enc)), "hashgrid_fwd_f16: NULL buffer");
+  IMMOCO_REQUIRE((enc_point_stride % 2) == 0 && (enc_level_stride % 2) == 0,
+                 "encoding strides must be even (float2 stores)");
+  if (n == 0) return IMMOCO_OK;
+  dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
+  const __half2* t = reinterpret_cast<const __half2*>(table_f16);
+  Lattice none{};
+  if (lv.dims == 2)
+    hashgrid_fwd_kernel<2, false, __half2><<<grid, block, 0, as_stream(stream)>>>(lv, coords, none, n, t, enc,
+                                                                                 enc_point_stride, enc_level_stride);
+  else
+    hashgrid_fwd_kernel<3, false, __half2><<<grid, block, 0, as_stream(stream)>>>(lv, coords, none, n, t, enc,
+                                                                                 enc_point_stride, enc_level_stride);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
 extern "C" int immoco_hashgrid_bwd(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
                                    const float* denc, int64_t enc_point_stride, int64_t enc_level_stride,
                                    float* dtable, void* stream) {

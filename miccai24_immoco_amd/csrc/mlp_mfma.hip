@@ -108,7 +108,8 @@ __device__ __forceinline__ f32x16 pre_tile(const float4* aw, int jt, int lane, c
 
 // ---------------------------------------------------------------------------------------------
 // forward: out[p][0..1] = W2 . act(W1 . enc[p])
-// (Forcing 4 waves/SIMD with a register cap spills and is slower: 0.133 vs 0.101 ms.)
+// (Forcing 4 waves/SIMD with a register cap spills and is slower: 0.133 vs 0.101 ms; getting there without
+// spills - one hidden tile live at a time, 90 registers, 1024 workgroups - changes nothing: 0.078 vs 0.080 ms.)
 template <int HID, int ACT>
 __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restrict__ in, int64_t ps, int64_t ls,
                                                            int64_t n, const float* __restrict__ w1,
@@ -178,13 +179,24 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
   for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = w2[i];
   __syncthreads();
 
+  // dW2: the narrow net (HID = 64, the motion INR on the critical path) keeps per-LANE partial sums
+  // dw2l[jt][g][o] += h[hidden drow(g,h)][point r] * dout[point r][o] over all of the wave's tiles and
+  // reduces them over the lanes once at the end (32 FMAs per tile instead of a 16-MFMA chain whose
+  // 32x32 result has two useful rows); the wide net has no registers for that (NJT*32 of them) and
+  // multiplies dout^T . h' on the matrix core.
+  constexpr bool LANE_DW2 = HID == 64;
   f32x16 dw1t[NJT];  // dW1^T tiles: rows k (features), col = hidden jt*32 + r
   float dw2a[NJT][2];
+  float dw2l[LANE_DW2 ? NJT : 1][16][2];
 #pragma unroll
   for (int jt = 0; jt < NJT; ++jt) {
     dw1t[jt] = (f32x16){0.f};
     dw2a[jt][0] = dw2a[jt][1] = 0.f;
   }
+#pragma unroll
+  for (int jt = 0; jt < (LANE_DW2 ? NJT : 1); ++jt)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dw2l[jt][g][0] = dw2l[jt][g][1] = 0.f;
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
   float nx[16];
@@ -218,13 +230,15 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // A fragments in accumulator-k order: et[g] = enc[point drow(g,h)][feature r], dt[g] = dout[point drow(g,h)][r]
     float et[16];
+    if (!LANE_DW2) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float4 q4 = *reinterpret_cast<const float4*>(te + r * TLD + 8 * a + 4 * h);
-      et[4 * a] = q4.x;
-      et[4 * a + 1] = q4.y;
-      et[4 * a + 2] = q4.z;
-      et[4 * a + 3] = q4.w;
+      for (int a = 0; a < 4; ++a) {
+        const float4 q4 = *reinterpret_cast<const float4*>(te + r * TLD + 8 * a + 4 * h);
+        et[4 * a] = q4.x;
+        et[4 * a + 1] = q4.y;
+        et[4 * a + 2] = q4.z;
+        et[4 * a + 3] = q4.w;
+      }
     }
     f32x16 denc = {0.f};
 #pragma unroll
@@ -242,6 +256,10 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
           const float hh = act_f<ACT>(pre[4 * a + b]);
           hv[4 * a + b] = hh;
           dp[4 * a + b] = fmaf(was[b], d.x, wbs[b] * d.y) * act_d<ACT>(hh);
+          if (LANE_DW2) {
+            dw2l[LANE_DW2 ? jt : 0][4 * a + b][0] = fmaf(hh, d.x, dw2l[LANE_DW2 ? jt : 0][4 * a + b][0]);
+            dw2l[LANE_DW2 ? jt : 0][4 * a + b][1] = fmaf(hh, d.y, dw2l[LANE_DW2 ? jt : 0][4 * a + b][1]);
+          }
         }
       }
       // d enc^T[k][p] += sum_j W1[j][k] dpre[j][p]
@@ -253,33 +271,52 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
         denc = mfma32(a.z, dp[4 * g4 + 2], denc);
         denc = mfma32(a.w, dp[4 * g4 + 3], denc);
       }
-      // ---- layout 2: h' = transpose(h) through the per-wave LDS tile
+      // ---- layout 2: transpose through the per-wave LDS tile
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous readers of the tile are done
+      if (LANE_DW2) {
+        // dpre' = transpose(dpre) is all that is left to do in this layout
 #pragma unroll
-      for (int g = 0; g < 16; ++g) tr[drow(g, h) * TLD + r] = hv[g];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const float w20 = w2s[jt * 32 + r], w21 = w2s[HID + jt * 32 + r];
-      float hp[16];
+        for (int g = 0; g < 16; ++g) tr[drow(g, h) * TLD + r] = dp[g];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dW1^T[k][j] += sum_p enc[p][k] dpre'[p][j]; both fragments come straight from the LDS tiles
+        // (no 16-register copies: the kernel sits at the 256-register budget of 2 waves/SIMD)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const float4 q4 = *reinterpret_cast<const float4*>(tr + r * TLD + 8 * a + 4 * h);
-        hp[4 * a] = q4.x;
-        hp[4 * a + 1] = q4.y;
-        hp[4 * a + 2] = q4.z;
-        hp[4 * a + 3] = q4.w;
+        for (int a = 0; a < 4; ++a) {
+          const float4 qd = *reinterpret_cast<const float4*>(tr + r * TLD + 8 * a + 4 * h);
+          const float4 qe = *reinterpret_cast<const float4*>(te + r * TLD + 8 * a + 4 * h);
+          dw1t[jt] = mfma32(qe.x, qd.x, dw1t[jt]);
+          dw1t[jt] = mfma32(qe.y, qd.y, dw1t[jt]);
+          dw1t[jt] = mfma32(qe.z, qd.z, dw1t[jt]);
+          dw1t[jt] = mfma32(qe.w, qd.w, dw1t[jt]);
+        }
+      } else {
+        // h' = transpose(h); dpre' is recomputed from it
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tr[drow(g, h) * TLD + r] = hv[g];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float w20 = w2s[jt * 32 + r], w21 = w2s[HID + jt * 32 + r];
+        float hp[16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float4 q4 = *reinterpret_cast<const float4*>(tr + r * TLD + 8 * a + 4 * h);
+          hp[4 * a] = q4.x;
+          hp[4 * a + 1] = q4.y;
+          hp[4 * a + 2] = q4.z;
+          hp[4 * a + 3] = q4.w;
+        }
+        f32x16 tmp = {0.f};
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          // dout of row point drow(g,h): re-read from LDS (broadcast) instead of holding 48 registers
+          const float2 dq = *reinterpret_cast<const float2*>(dos + 2 * drow(g, h));
+          const float dpt = fmaf(w20, dq.x, w21 * dq.y) * act_d<ACT>(hp[g]);
+          const float dtg = r == 0 ? dq.x : (r == 1 ? dq.y : 0.f);
+          dw1t[jt] = mfma32(et[g], dpt, dw1t[jt]);  // dW1^T[k][j] += sum_p enc[p][k] dpre'[p][j]
+          tmp = mfma32(dtg, hp[g], tmp);            // dW2^T[o][j] += sum_p dout[p][o] h'[p][j]
+        }
+        dw2a[jt][0] += tmp[0];  // row o = 0 (lanes h = 0)
+        dw2a[jt][1] += tmp[1];  // row o = 1
       }
-      f32x16 tmp = {0.f};
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        // dout of row point drow(g,h): re-read from LDS (broadcast) instead of holding 48 registers
-        const float2 dq = *reinterpret_cast<const float2*>(dos + 2 * drow(g, h));
-        const float dpt = fmaf(w20, dq.x, w21 * dq.y) * act_d<ACT>(hp[g]);
-        const float dtg = r == 0 ? dq.x : (r == 1 ? dq.y : 0.f);
-        dw1t[jt] = mfma32(et[g], dpt, dw1t[jt]);  // dW1^T[k][j] += sum_p enc[p][k] dpre'[p][j]
-        tmp = mfma32(dtg, hp[g], tmp);            // dW2^T[o][j] += sum_p dout[p][o] h'[p][j]
-      }
-      dw2a[jt][0] += tmp[0];  // row o = 0 (lanes h = 0)
-      dw2a[jt][1] += tmp[1];  // row o = 1
     }
     // ---- d enc: rows = feature (g&3) + 8(g>>2) + 4h, col = point
     if (valid) {
@@ -306,7 +343,30 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
       const int idx = it * 64 + lane;  // (hidden = idx>>5, feature = idx&31) of this 32x32 tile
       unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, tr[(idx >> 5) * TLD + (idx & 31)]);
     }
-    if (h == 0) {
+    if (LANE_DW2) {
+      // sum the per-lane partials over the 32 points of each lane half, stage the 2 x 32 sums in LDS and
+      // flush them with two 128-byte atomics (one atomic per (hidden, output) pair - 64 two-lane
+      // instructions per wave on the same four cache lines - cost 0.3 ms of serialised L2 atomics)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float v0 = dw2l[LANE_DW2 ? jt : 0][g][0], v1 = dw2l[LANE_DW2 ? jt : 0][g][1];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {
+          v0 += __shfl_xor(v0, m, 64);
+          v1 += __shfl_xor(v1, m, 64);
+        }
+        if (r == 0) {
+          dos[drow(g, h)] = v0;
+          dos[32 + drow(g, h)] = v1;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h == 0) {
+        unsafeAtomicAdd(dw2 + jt * 32 + r, dos[r]);
+        unsafeAtomicAdd(dw2 + HID + jt * 32 + r, dos[32 + r]);
+      }
+    } else if (h == 0) {
       unsafeAtomicAdd(dw2 + jt * 32 + r, dw2a[jt][0]);
       unsafeAtomicAdd(dw2 + HID + jt * 32 + r, dw2a[jt][1]);
     }

@@ -52,6 +52,14 @@ def test_hashgrid_fwd_bit_exact_and_bwd(env, dims):
     enc2 = torch.empty(16, n, 2, device="cuda")
     L.check(L.lib().immoco_hashgrid_fwd(C.byref(cfg), L.ptr(cd), n, L.ptr(td), L.ptr(enc2), 2, 2 * n, L.stream_ptr()))
     assert torch.equal(enc2.cpu().permute(1, 0, 2).reshape(n, 32), ref)
+    # fp16 table (tiny-cuda-nn's parameter precision): entries widened to fp32, same arithmetic => bit-exact
+    # against the oracle fed with the rounded table
+    th = table.half()
+    thd = dev(th)
+    enc3 = torch.empty(n, 32, device="cuda")
+    L.check(L.lib().immoco_hashgrid_fwd_f16(C.byref(cfg), L.ptr(cd), n, L.ptr(thd), L.ptr(enc3), 32, 2,
+                                            L.stream_ptr()))
+    assert torch.equal(enc3.cpu(), plan.encode(th.float()))
     # backward: scatter-add of weighted gradients
     denc = torch.randn(n, 32, generator=g)
     t = table.clone().requires_grad_(True)
