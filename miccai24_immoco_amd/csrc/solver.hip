@@ -152,7 +152,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
                     return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
                                           s->enc_mot, g_w1m, g_w2m, q);
-                  }, 1});
+                  }});  // before the fork: the image chain's MFMA-bound MLP backward then runs beside the
+                        // gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
                     if (s->plan_mot) return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q);
                     return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
