@@ -9,7 +9,8 @@
 // Plan (once per solver): a transposed index ("CSR by slot"): for every table slot the list of its
 // contributions, slot-sorted, built on the GPU (count -> hipCUB exclusive scan -> fill), plus a
 // host-built list of work items.  An entry is 8 bytes: {point (relative to its part) << 11 | slot
-// (relative to its 2048-slot block), interpolation weight fp32}.  Earlier versions stored 4 bytes
+// (relative to its 2048-slot block), interpolation weight fp32}; a "twin" entry (sign bit of the weight
+// set) stands for both dim-0 corners of its point: even slot | swap bit, weight of the other dimensions.  Earlier versions stored 4 bytes
 // (corner | col | row | m) and recomputed slot and weight per entry from LDS axis tables: an
 // ablation on MI355X showed that this decode/hash/weight ALU work was 70 % of the kernel
 // (0.63 ms with, 0.45 ms without the gathers), so the plan now pays 4 more bytes of (otherwise
@@ -29,6 +30,7 @@
 // slice hot.  Each part writes its own partial gradient table; the Adam kernel sums them.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <vector>
 
 #include "kernels.hpp"
@@ -64,7 +66,7 @@ struct AxisPtrs {
 // one thread per (point, level): count / fill all 2^D corners.
 template <int D, bool FILL>
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs<D> ax, int nM, int H, int W,
-                                                             int n_parts, int64_t part_size,
+                                                             int n_parts, int64_t part_size, bool pair_merge,
                                                              uint32_t* __restrict__ counts_or_cursor,
                                                              const uint32_t* __restrict__ offs,
                                                              uint2* __restrict__ entries) {
@@ -85,22 +87,60 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
   const uint32_t part = (uint32_t)(p / part_size);
   const uint32_t p_rel = (uint32_t)(p - (int64_t)part * part_size);
 #pragma unroll
-  for (int corner = 0; corner < (1 << D); ++corner) {
-    uint32_t cc[D];
-    float w = 1.0f;
+  for (int pair = 0; pair < (1 << (D - 1)); ++pair) {
+    uint32_t idx[2];
+    float w[2];
+    float wrest = 1.0f;  // product of the factors of dimensions >= 1 (shared by the two dim-0 corners)
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const bool hi = (corner >> d) & 1;
-      cc[d] = cell[d] + (hi ? 1u : 0u);
-      w *= hi ? fr[d] : 1.0f - fr[d];
+    for (int b0 = 0; b0 < 2; ++b0) {
+      const int corner = 2 * pair + b0;
+      uint32_t cc[D];
+      float wc = 1.0f, wr = 1.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const bool hi = (corner >> d) & 1;
+        cc[d] = cell[d] + (hi ? 1u : 0u);
+        const float f = hi ? fr[d] : 1.0f - fr[d];
+        wc *= f;
+        if (d > 0) wr *= f;
+      }
+      idx[b0] = grid_index<D>(cc, size, res, hashed, pow2);
+      w[b0] = wc;
+      wrest = wr;
     }
-    const uint32_t idx = grid_index<D>(cc, size, res, hashed, pow2);
-    // counter index ordered by (level, part, slot)
-    const uint32_t key = lv.offset[l] * (uint32_t)n_parts + part * size + idx;
-    const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
-    if (FILL)
-      entries[offs[key] + pos] = make_uint2((p_rel << SLOT_BITS) | (idx & (SLOTS_PER_ITEM - 1)), __float_as_uint(w));
+    const uint32_t kbase = lv.offset[l] * (uint32_t)n_parts + part * size;  // counters ordered by (level, part, slot)
+    if (pair_merge && (idx[0] ^ idx[1]) == 1u) {
+      // twin entry: both dim-0 corners of this point land in ONE aligned slot pair (see hashgrid.hip).
+      // Stored once at the even slot: slot LSB = 1 when the even slot belongs to the HIGH dim-0 corner,
+      // weight = -(product of the other dimensions' factors); the dim-0 fraction comes from a per-level
+      // table at run time.  One dL/denc gather then serves two slots.
+      const uint32_t even = idx[0] & ~1u, swap = idx[0] & 1u;
+      const uint32_t key = kbase + even;
+      const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
+      if (FILL)
+        entries[offs[key] + pos] = make_uint2((p_rel << SLOT_BITS) | (even & (SLOTS_PER_ITEM - 1)) | swap,
+                                              __float_as_uint(wrest) | 0x80000000u);
+    } else {
+#pragma unroll
+      for (int b0 = 0; b0 < 2; ++b0) {
+        const uint32_t key = kbase + idx[b0];
+        const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
+        if (FILL)
+          entries[offs[key] + pos] =
+              make_uint2((p_rel << SLOT_BITS) | (idx[b0] & (SLOTS_PER_ITEM - 1)), __float_as_uint(w[b0]));
+      }
+    }
   }
+}
+
+// dim-0 interpolation fraction per (level, dim-0 lattice index): the run-time half of a twin entry's weights
+__global__ void csr_f0_kernel(Levels lv, const float* __restrict__ ax0, int n0, float* __restrict__ f0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lv.n_levels * n0) return;
+  uint32_t cell;
+  float fr;
+  pos_fract(ax0[i % n0], lv.scale[i / n0], cell, fr);
+  f0[i] = fr;
 }
 
 struct BwdItem {
@@ -134,28 +174,34 @@ __global__ __launch_bounds__(256) void csr_permute_kernel(const BwdItem* __restr
 // History (MI355X, 320x320x10): v1 lane-per-entry LDS atomics 1.86 ms; v2 LDS-staged tiles 0.87 ms
 // (latency-bound, SQ_WAIT_ANY 61 %); v3 per-thread runs of 16 entries, 4-byte entries decoded on
 // the fly 0.63 ms; v4 precomputed 8-byte entries, thread-contiguous loads 0.79 ms; v5 (this kernel)
-// the same in the transposed wave-chunk layout 0.59 ms.  Tried without gain: slot-pair entries that
-// share one gather between the two dim-0 corners (0.61 ms on v3), twin corners stored adjacently
-// (0.59 ms on v5).  rocprof: TA busy 94 %, TA_ADDR_STALLED_BY_TC 82 %, TCP_PENDING_STALL 280 M cycles
+// the same in the transposed wave-chunk layout 0.59 ms; v6 twin entries (the two dim-0 corners of a point
+// that fall into one aligned slot pair share ONE entry and ONE gather: 19.5 % fewer entries) 0.54 ms
+// isolated, 0.65 instead of 0.78 ms beside the image chain.  The same idea cost time on v3 (0.61 ms), where
+// entries were decoded on the fly and the kernel was ALU-bound; twin corners merely stored adjacently
+// gained nothing (0.59 ms on v5).  rocprof: TA busy 94 %, TA_ADDR_STALLED_BY_TC 82 %, TCP_PENDING_STALL 280 M cycles
 // -> both gather kernels sit at the L1 miss-concurrency limit (~175 G L2 requests/s chip-wide).
 constexpr int EPT = 16;                  // entries per thread per chunk
-constexpr int CHUNK_ENTRIES = 256 * EPT;  // 4096
 
-template <int DIMS>  // DIMS only names the instantiation (2: image grid, 3: motion grid) in profiles
+// PAIR: the plan holds twin entries (motion grid): a run is a slot PAIR and carries four sums.
+template <int DIMS, bool PAIR>  // DIMS names the instantiation (2: image grid, 3: motion grid) in profiles
 __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
                                                       const uint2* __restrict__ entries,
                                                       const float2* __restrict__ denc /*[L][n]*/,
                                                       float* __restrict__ dtable, int64_t part_stride,
-                                                      int zeroed) {
+                                                      int zeroed, const float* __restrict__ f0tab, int n0,
+                                                      uint32_t hw, float inv_hw) {
   __shared__ float acc[2 * SLOTS_PER_ITEM];
+  __shared__ float f0s[PAIR ? 256 : 1];
   const BwdItem it = items[blockIdx.x];
   if (it.n_wc == 0) return;  // padding item of the XCD interleave
   const int tid = threadIdx.x;
   for (int i = tid; i < 2 * (int)it.ns; i += 256) acc[i] = 0.f;
+  if (PAIR && tid < n0) f0s[tid] = f0tab[it.level * n0 + tid];
   __syncthreads();
   const uint32_t part = it.part_shared & 0xFFFFu;
   const float2* __restrict__ dl = denc + (int64_t)it.level * n_points + (int64_t)part * part_size;
+  const uint32_t p_off = (uint32_t)((int64_t)part * part_size);
   const int lane = tid & 63, wave = tid >> 6;
   const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(entries + it.pe0);
   uint4 q[EPT / 2];
@@ -180,23 +226,61 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
     float2 g[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) g[k] = dl[key[k] >> SLOT_BITS];
-    // run-length accumulate
-    uint32_t cur = key[0] & (SLOTS_PER_ITEM - 1);
-    float s0 = 0.f, s1 = 0.f;
+    if (PAIR) {
+      // run-length accumulate over slot pairs: (even.x, even.y, odd.x, odd.y) = acc[4*pair .. 4*pair+3]
+      uint32_t cur = (key[0] & (SLOTS_PER_ITEM - 1)) >> 1;
+      float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1);
-      if (loc != cur) {
-        atomicAdd(&acc[2 * cur], s0);
-        atomicAdd(&acc[2 * cur + 1], s1);
-        cur = loc;
-        s0 = s1 = 0.f;
+      for (int k = 0; k < EPT; ++k) {
+        const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1), pr = loc >> 1;
+        const bool twin = __float_as_uint(wt[k]) >> 31, odd = loc & 1u;
+        const float w = fabsf(wt[k]);
+        // dim-0 lattice index of the point (exact: p < 2^24, one correction step each way)
+        const uint32_t pnt = p_off + (key[k] >> SLOT_BITS);
+        uint32_t i0 = (uint32_t)((float)pnt * inv_hw);
+        i0 -= (i0 * hw > pnt) ? 1u : 0u;
+        i0 += ((i0 + 1u) * hw <= pnt) ? 1u : 0u;
+        const float f = f0s[twin ? i0 : 0u];
+        // twin: the even slot takes the low dim-0 corner (1 - f) unless the swap bit (odd) is set
+        const float fe = odd ? f : 1.f - f;
+        const float we = twin ? w * fe : (odd ? 0.f : w);
+        const float wo = twin ? w * (1.f - fe) : (odd ? w : 0.f);
+        if (pr != cur) {
+          atomicAdd(&acc[4 * cur], e0);
+          atomicAdd(&acc[4 * cur + 1], e1);
+          atomicAdd(&acc[4 * cur + 2], o0);
+          atomicAdd(&acc[4 * cur + 3], o1);
+          cur = pr;
+          e0 = e1 = o0 = o1 = 0.f;
+        }
+        e0 = fmaf(we, g[k].x, e0);
+        e1 = fmaf(we, g[k].y, e1);
+        o0 = fmaf(wo, g[k].x, o0);
+        o1 = fmaf(wo, g[k].y, o1);
       }
-      s0 = fmaf(wt[k], g[k].x, s0);
-      s1 = fmaf(wt[k], g[k].y, s1);
+      atomicAdd(&acc[4 * cur], e0);
+      atomicAdd(&acc[4 * cur + 1], e1);
+      atomicAdd(&acc[4 * cur + 2], o0);
+      atomicAdd(&acc[4 * cur + 3], o1);
+    } else {
+      // run-length accumulate
+      uint32_t cur = key[0] & (SLOTS_PER_ITEM - 1);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1);
+        if (loc != cur) {
+          atomicAdd(&acc[2 * cur], s0);
+          atomicAdd(&acc[2 * cur + 1], s1);
+          cur = loc;
+          s0 = s1 = 0.f;
+        }
+        s0 = fmaf(wt[k], g[k].x, s0);
+        s1 = fmaf(wt[k], g[k].y, s1);
+      }
+      atomicAdd(&acc[2 * cur], s0);
+      atomicAdd(&acc[2 * cur + 1], s1);
     }
-    atomicAdd(&acc[2 * cur], s0);
-    atomicAdd(&acc[2 * cur + 1], s1);
   }
   __syncthreads();
   float* __restrict__ out = dtable + (size_t)part * part_stride + (size_t)it.s0 * 2;
@@ -233,12 +317,15 @@ struct CsrPlan {
   uint64_t n_entries = 0;
   int64_t bytes = 0;
   uint32_t shared_slot_end = 0;  // slots < this may belong to "shared" (atomic-flush) items
+  bool pair_merge = false;       // twin entries present (3-D grids with <= 256 dim-0 lattice values)
+  float* f0tab = nullptr;        // [n_levels][axn[0]] dim-0 fractions for the twin entries
 };
 
 void csr_plan_free(CsrPlan* p) {
   if (!p) return;
   if (p->entries) hipFree(p->entries);
   if (p->items) hipFree(p->items);
+  if (p->f0tab) hipFree(p->f0tab);
   delete p;
 }
 
@@ -261,7 +348,16 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   IMMOCO_CHECK_HIP(hipMalloc((void**)&offs, (n_cnt + 1) * 4));
   IMMOCO_CHECK_HIP(hipMemsetAsync(counts, 0, (n_cnt + 1) * 4, st));
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels);
-  csr_count_fill_kernel<D, false><<<grid, 256, 0, st>>>(lv, ax, pl->nM, pl->H, pl->W, NP, pl->part_size, counts,
+  // twin entries: 3-D lattice whose dim 0 is the slowest axis (m), small enough for the LDS table and
+  // for the float-assisted index division of the kernel
+  pl->pair_merge = D == 3 && pl->axn[0] <= 256 && n < (1 << 24) && !getenv("IMMOCO_CSR_NO_TWIN");
+  if (pl->pair_merge) {
+    const int nf = lv.n_levels * pl->axn[0];
+    IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->f0tab, (size_t)nf * sizeof(float)));
+    csr_f0_kernel<<<cdiv(nf, 256), 256, 0, st>>>(lv, pl->axes[0], pl->axn[0], pl->f0tab);
+    IMMOCO_LAUNCH_CHECK();
+  }
+  csr_count_fill_kernel<D, false><<<grid, 256, 0, st>>>(lv, ax, pl->nM, pl->H, pl->W, NP, pl->part_size, pl->pair_merge, counts,
                                                        nullptr, nullptr);
   IMMOCO_LAUNCH_CHECK();
   IMMOCO_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, counts, offs, (int)n_cnt + 1, st));
@@ -271,11 +367,13 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   IMMOCO_CHECK_HIP(hipMemcpyAsync(h_offs.data(), offs, h_offs.size() * 4, hipMemcpyDeviceToHost, st));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(st));
   pl->n_entries = h_offs[n_cnt];
-  IMMOCO_REQUIRE(pl->n_entries == (uint64_t)n * lv.n_levels * (1u << D), "csr plan: entry count mismatch");
+  IMMOCO_REQUIRE(pl->pair_merge ? pl->n_entries <= (uint64_t)n * lv.n_levels * (1u << D)
+                                : pl->n_entries == (uint64_t)n * lv.n_levels * (1u << D),
+                 "csr plan: entry count mismatch");
   uint2* sorted = nullptr;  // slot-sorted build array, permuted into the final layout below
   IMMOCO_CHECK_HIP(hipMalloc((void**)&sorted, (size_t)pl->n_entries * 8));
   IMMOCO_CHECK_HIP(hipMemsetAsync(counts, 0, (n_cnt + 1) * 4, st));
-  csr_count_fill_kernel<D, true><<<grid, 256, 0, st>>>(lv, ax, pl->nM, pl->H, pl->W, NP, pl->part_size, counts, offs,
+  csr_count_fill_kernel<D, true><<<grid, 256, 0, st>>>(lv, ax, pl->nM, pl->H, pl->W, NP, pl->part_size, pl->pair_merge, counts, offs,
                                                       sorted);
   IMMOCO_LAUNCH_CHECK();
   // Work items per part: one aligned block of SLOTS_PER_ITEM slots of one (level, part); a block
@@ -388,12 +486,15 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
                    hipStream_t st) {
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
-  if (pl->dims == 3)
-    csr_bwd_kernel<3><<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,
-                                                   (const float2*)denc_level_major, dtable, part_stride, zeroed);
-  else
-    csr_bwd_kernel<2><<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,
-                                                   (const float2*)denc_level_major, dtable, part_stride, zeroed);
+  const uint32_t hw = (uint32_t)pl->H * (uint32_t)pl->W;
+#define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
+  csr_bwd_kernel<D, PAIR><<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,                 \
+                                                       (const float2*)denc_level_major, dtable, part_stride,     \
+                                                       zeroed, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw)
+  if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);
+  else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false);
+  else IMMOCO_CSR_BWD(2, false);
+#undef IMMOCO_CSR_BWD
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
