@@ -203,7 +203,8 @@ typedef struct immoco_solver_cfg {
   int32_t atomic_scatter; /* 1: hash-grid backward by global float atomics (slow reference path
                              kept for A/B measurements); 0: transposed-index gather (default) */
   int32_t grad_parts;     /* point-range parts of the motion grid's transposed index (1, 2, 4 or 8;
-                             0 = default 4): each XCD keeps a 8/parts MB slice of dL/denc in its L2 */
+                             0 = chosen from the lattice size so that one level slice of dL/denc per
+                             part is ~2 MB, the share of an XCD's L2: 4 at 320x320x10, 8 at 640x640x20) */
   int32_t serial_chains;  /* 1: run the image-INR and motion-INR kernel chains one after the other
                              (default 0: two concurrent branches of the graph) */
   int32_t table_fp16;     /* 1: gather the hash-grid features from fp16 shadows of the tables (what
