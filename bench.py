@@ -227,8 +227,10 @@ def main():
                                             C.c_void_p(torch.cuda.current_stream().cuda_stream),
                                             C.byref(probe_ms)), "probe_gather")
         ceiling = 1024000 * 64 / (probe_ms.value * 1e-3) / 1e9
-        n_req = nM * H * W * 16 * 8
-        gather = {"requests_per_launch": n_req, "achieved_Greq_s": round(n_req / (ms * 1e-3) / 1e9, 1),
+        n_alg = nM * H * W * 16 * 8                    # one contribution per (point, corner, level)
+        n_req = int(L.lib().immoco_solver_plan_entries(solver.handle, 1)) or n_alg   # gathers issued (twins once)
+        gather = {"contributions_per_launch": n_alg, "requests_per_launch": n_req,
+                  "achieved_Greq_s": round(n_req / (ms * 1e-3) / 1e9, 1),
                   "achieved_isolated_Greq_s": round(n_req / (dict(phases)[name] * 1e-3) / 1e9, 1),
                   "ceiling_Greq_s": round(ceiling, 1), "frac": round(n_req / (ms * 1e-3) / 1e9 / ceiling, 4),
                   "frac_isolated": round(n_req / (dict(phases)[name] * 1e-3) / 1e9 / ceiling, 4),

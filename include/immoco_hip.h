@@ -275,6 +275,10 @@ int immoco_solver_set_graph(immoco_solver_t s, int32_t use_graph);
 /* 1 when the last solve replayed a captured hipGraph, 0 when it launched eagerly. */
 int immoco_solver_graph_active(immoco_solver_t s);
 
+/* Entries of a transposed hash-grid index (which: 0 image grid, 1 motion grid) = dL/denc gathers one
+ * encode-backward launch issues (twin entries count once); 0 before immoco_solver_set_lattice. */
+int64_t immoco_solver_plan_entries(immoco_solver_t s, int32_t which);
+
 /* Measurement aid (bench.py `roofline.gather_ceiling`), no counterpart in the reference: the rate the
  * chip sustains for the request shape of the hash-grid kernels - n_lanes lanes, each issuing
  * loads_per_lane independent bytes_per_load-byte (8 or 16) loads at pseudo-random aligned offsets of a

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "immoco_solver_graph_active": (C.c_int, [_P]),
     "immoco_solver_dominant_kernel_ms": (C.c_float, [_P]),
     "immoco_solver_set_graph": (C.c_int, [_P, _I32]),
+    "immoco_solver_plan_entries": (C.c_int64, [_P, _I32]),
     "immoco_probe_gather": (C.c_int, [_I64, _I32, _I64, _I32, _I32, _P, C.POINTER(C.c_float)]),
 }
 

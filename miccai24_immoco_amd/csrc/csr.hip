@@ -476,6 +476,7 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
 }
 
 int64_t csr_plan_bytes(const CsrPlan* p) { return p ? p->bytes : 0; }
+int64_t csr_plan_entries(const CsrPlan* p) { return p ? (int64_t)p->n_entries : 0; }
 int csr_plan_parts(const CsrPlan* p) { return p ? p->n_parts : 1; }
 uint32_t csr_plan_shared_slot_end(const CsrPlan* p) { return p ? p->shared_slot_end : 0; }
 

@@ -86,6 +86,7 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
                    int n_parts, CsrPlan** out, hipStream_t st);
 void csr_plan_free(CsrPlan* p);
 int64_t csr_plan_bytes(const CsrPlan* p);
+int64_t csr_plan_entries(const CsrPlan* p);
 int csr_plan_parts(const CsrPlan* p);
 uint32_t csr_plan_shared_slot_end(const CsrPlan* p);  // table slots below this need zeroing by the consumer
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,

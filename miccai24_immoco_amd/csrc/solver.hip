@@ -514,6 +514,11 @@ extern "C" int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const flo
   return IMMOCO_OK;
 }
 
+extern "C" int64_t immoco_solver_plan_entries(immoco_solver_t s, int32_t which) {
+  if (!s) return -1;
+  return csr_plan_entries(which == 0 ? s->plan_img : s->plan_mot);
+}
+
 extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group, const float* params_image,
                                      const float* params_motion, float* out_image, float* out_kspace,
                                      void* stream) {

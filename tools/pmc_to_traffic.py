@@ -16,7 +16,7 @@ PHASE = [("hashgrid_fwd_kernel<2", "image_encode_fwd"), ("hashgrid_fwd_kernel<3"
          ("mlp_fwd_mfma_kernel<256", "image_mlp_fwd"), ("mlp_fwd_mfma_kernel<64", "motion_mlp_fwd"),
          ("motion_warp_fwd_kernel", "motion_warp_fwd"), ("motion_warp_bwd", "motion_warp_bwd"),
          ("mlp_bwd_mfma_kernel<256", "image_mlp_bwd"), ("mlp_bwd_mfma_kernel<64", "motion_mlp_bwd"),
-         ("csr_bwd_kernel<3>", "motion_encode_bwd"), ("csr_bwd_kernel<2>", "image_encode_bwd"),
+         ("csr_bwd_kernel<3", "motion_encode_bwd"), ("csr_bwd_kernel<2", "image_encode_bwd"),
          ("select_dc_seed_kernel", "select_dc_seed"), ("ge_loss_kernel", "image_grad_init_ge")]
 agg = {}
 for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
