@@ -158,6 +158,34 @@ def test_inr_module_vs_oracle(env, which):
         assert (a - b).abs().max() <= 2e-4 * a.abs().max(), ((a - b).abs().max(), a.abs().max())
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+def test_inr_module_other_grid_config_vs_oracle(env, dims):
+    """The tcnn-compatible module is not tied to the reference's grid numbers: a smaller hash map, another
+    base resolution and a non-power-of-two per-level scale (dense AND hashed levels change) vs the oracle."""
+    pkg, L, orc = env
+    enc = dict(pkg.encoding_config, log2_hashmap_size=14, base_resolution=6, per_level_scale=1.5)
+    net = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+           "n_hidden_layers": 1}
+    inr = pkg.NetworkWithInputEncoding(dims, 2, enc, net, seed=11)
+    ref = orc.OracleINR(dims, 2, enc, net, seed=11)
+    assert inr.params.numel() == ref.params.numel()
+    with torch.no_grad():
+        ref.params[ref.mlp.n_params:] *= 1000
+        inr.params.copy_(ref.params.cuda())
+    x = orc.make_grids((2, 7, 10) if dims == 3 else (12, 15))
+    out_ref = ref(x)
+    out_ref.square().sum().backward()
+    out = inr(x.cuda())
+    out.square().sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    gr, gg = ref.params.grad, inr.params.grad.cpu()
+    nw = ref.mlp.n_params
+    for a, b in ((gr[:nw], gg[:nw]), (gr[nw:], gg[nw:])):
+        assert (a - b).abs().max() <= 2e-4 * a.abs().max(), ((a - b).abs().max(), a.abs().max())
+    with pytest.raises(L.ImmocoError):
+        pkg.NetworkWithInputEncoding(dims, 2, dict(enc, interpolation="Smoothstep"), net)
+
+
 # ----------------------------------------------------------------------- warp
 def test_warp_fwd_bwd_vs_grid_sample(env):
     pkg, L, orc = env
@@ -591,6 +619,22 @@ def test_solver_non_square_vs_oracle(env):
     masks = torch.stack([(cg == m + 1).long()[None, :].expand(H, W) for m in range(nM)]).contiguous()
     hist = _oracle_first_losses(orc, ksp, masks, 10)
     _, _, loss = pkg.imcoco_motion_correction(ksp.cuda(), masks.cuda(), iters=10, return_loss=True)
+    np.testing.assert_allclose(loss.cpu().numpy()[:5], hist[:5], rtol=2e-5)
+    np.testing.assert_allclose(loss.cpu().numpy(), hist, rtol=5e-3)
+
+
+def test_solver_single_group_vs_oracle(env):
+    """nM = 1: make_grids gives the single motion coordinate m = -1 (immoco.py:48-53 with one group); also
+    the smallest dim-0 table of the transposed index's twin entries."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd import synth
+    H = 32
+    ksp = orc.FFT(synth.phantom(H, H, 9))
+    cg = torch.zeros(H, dtype=torch.long)
+    cg[11:17] = 1
+    masks = (cg == 1).long()[None, None, :].expand(1, H, H).contiguous()
+    hist = _oracle_first_losses(orc, ksp, masks, 12)
+    _, _, loss = pkg.imcoco_motion_correction(ksp.cuda(), masks.cuda(), iters=12, return_loss=True)
     np.testing.assert_allclose(loss.cpu().numpy()[:5], hist[:5], rtol=2e-5)
     np.testing.assert_allclose(loss.cpu().numpy(), hist, rtol=5e-3)
 
