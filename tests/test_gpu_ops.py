@@ -843,3 +843,23 @@ def test_batch_solve_matches_single_slices(env):
         pkg.imcoco_motion_correction_batch(ksp, masks[:2], iters=30)
     with pytest.raises(L.ImmocoError):
         pkg.imcoco_motion_correction_batch(ksp.cpu(), masks, iters=30)
+
+
+def test_probe_and_batch_argument_checks(env):
+    """Measurement/batch entry points: argument errors come back as status codes with a message."""
+    pkg, L, orc = env
+    ms = C.c_float()
+    st = L.stream_ptr()
+    assert L.lib().immoco_probe_gather(1 << 20, 8, 256 * 64, 8, 2, st, C.byref(ms)) == 0 and ms.value > 0
+    for bad in ((3 << 20, 8, 256, 8, 1), (1 << 20, 12, 256, 8, 1), (1 << 20, 8, 100, 8, 1), (1 << 20, 8, 256, 6, 1)):
+        assert L.lib().immoco_probe_gather(*bad, st, C.byref(ms)) != 0
+        assert len(L.last_error()) > 0
+    from miccai24_immoco_amd.models.immoco import get_solver
+    s = get_solver(torch.device("cuda", 0), 32, 32, 2)
+    assert L.lib().immoco_solver_plan_entries(s.handle, 1) > 0
+    assert L.lib().immoco_solver_plan_entries(s.handle, 1) <= 2 * 32 * 32 * 16 * 8
+    lam = (C.c_float * 10)(*([0.01] * 10))
+    assert L.lib().immoco_solver_solve_batch(s.handle, 0, None, None, None, None, None, None, 10, 1e-2, lam, 0,
+                                             None, None, None, st) == 0          # empty batch: nothing to do
+    assert L.lib().immoco_solver_solve_batch(s.handle, 1, None, None, None, None, None, None, 10, 1e-2, lam, 0,
+                                             None, None, None, st) != 0          # NULL buffers are refused
