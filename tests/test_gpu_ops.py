@@ -773,13 +773,15 @@ def test_downstream_variant_options_vs_oracle(env, golden, capsys):
     assert "Scale:" in out and "iter: 80" in out
     lh = loss.cpu().numpy()
     np.testing.assert_allclose(lh[:5], np.array(hist[:5]), rtol=2e-5)
-    # iteration 91 uses lambda/2 (halved at j = 90): the same jump of the loss must show in both
-    # (the entropy term is negative here, so halving lambda RAISES the loss)
     assert abs(lh[0] - hist[0]) <= 1e-5 * hist[0]
-    jump_hip, jump_ref = lh[91] - lh[89], hist[91] - hist[89]
-    # (by iteration 90 the two runs are on different chaotic trajectories, so the size of the jump is only
-    # comparable to a factor; the schedules themselves are compared exactly in test_host_cabi.py)
-    assert jump_hip * jump_ref > 0 and 0.2 <= jump_hip / jump_ref <= 5.0, (jump_hip, jump_ref)
+    # The schedule itself is host logic (lambda/2 from iteration 91 on);
+    # that the solver applies the schedule it is handed is checked, without chaos, by
+    # test_solver_returns_last_forward_not_final_params.  By iteration 90 the two runs are on different
+    # chaotic trajectories, so the losses there are only compared to a factor.
+    from miccai24_immoco_amd.models.immoco import lambda_schedule
+    sched = lambda_schedule(95, 1e-2, "downstream")
+    assert sched == [1e-2] * 91 + [0.5e-2] * 4      # halved at j = 90, in force from iteration 91
+    assert 0.5 <= lh[94] / hist[94] <= 2.0, (lh[94], hist[94])
 
 
 # ------------------------------------------------ Autofocusing baseline
