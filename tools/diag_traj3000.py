@@ -17,8 +17,21 @@ cg = masks_to_col_group(masks)
 pi, pm = sol.init_params()
 ai = torch.zeros(2 * pi.numel(), device="cuda"); am = torch.zeros(2 * pm.numel(), device="cuda")
 lam = lambda_schedule(3000, 1e-2)
-seg = 125
-for a in range(0, 3000, seg):
-    img, kf, loss = sol.solve(kin, cg, pi, pm, ai, am, seg, 1e-2, lam[a:a + seg], step0=a, want_loss=True)
-    lh = loss.cpu().numpy()
-    print(a + seg - 1, "loss %.4g" % lh[-1], "lambda %.3g" % lam[a + seg - 1], "psnr %.3f" % crop_psnr(img.abs().cpu(), s["gt"].abs()), flush=True)
+# The oracle (tools/oracle_c2.py) logs loss and PSNR of the forward pass of iterations 0, 25, 50, ...: solve in
+# segments that END at those iterations (the solver returns the tensors of a segment's last forward pass).
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rows = []
+for rep in range(reps):
+    pi, pm = sol.init_params()
+    ai.zero_(); am.zero_()
+    a, out = 0, []
+    for end in [0] + list(range(25, 3000, 25)) + [2999]:
+        n = end - a + 1
+        img, kf, loss = sol.solve(kin, cg, pi, pm, ai, am, n, 1e-2, lam[a:a + n], step0=a, want_loss=True)
+        out.append((end, float(loss[-1]), crop_psnr(img.abs().cpu(), s["gt"].abs())))
+        a = end + 1
+    rows.append(out)
+    print("rep", rep, " ".join(f"{e}:{l:.4g}/{p:.2f}" for e, l, p in out[::8]), flush=True)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"traj3000_hip_slice{idx}.npz"),
+                    iters=np.array([e for e, _, _ in rows[0]]), loss=np.array([[l for _, l, _ in r] for r in rows]),
+                    psnr=np.array([[p for _, _, p in r] for r in rows]))
