@@ -52,6 +52,11 @@ int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, 
 // kspace.hip
 int fft2c(const float* in, float* out, int batch, int H, int W, int mode, hipStream_t st);
 int fft_exec_inplace(float* buf, int batch, int H, int W, bool inverse, hipStream_t st);  // raw, no shifts
+int fft_fwd_to_transposed(float* in, float* out_t, int B, int H, int W, hipStream_t st);      // -> [W][B][H]
+int fft_adj_from_transposed(float* in_t, float* out, int B, int H, int W, hipStream_t st);  // [W][B][H] ->
+int launch_transpose_c64(const float* in, float* out, int H, int W, hipStream_t st);
+int launch_select_dc_seed_t(float* fft_t, const int32_t* col_group, const float* kin_t, int nM, int H, int W,
+                            float* kout_t, float* loss_hist, const int32_t* iter_dev, hipStream_t st);
 int launch_kspace_select(const float* kall, const int32_t* col_group, int nM, int H, int W, float* kout,
                          hipStream_t st);
 int launch_dc_loss(const float* k, const float* kin, int H, int W, float* loss, float* dk, hipStream_t st);

@@ -41,6 +41,7 @@ struct immoco_solver {
   // device workspace
   float *enc_img = nullptr, *enc_mot = nullptr, *image = nullptr, *o_mot = nullptr, *t_mot = nullptr;
   float *fftbuf = nullptr, *dimage = nullptr, *grad_img = nullptr, *grad_mot = nullptr, *kout = nullptr;
+  float *fft_t = nullptr, *kin_t = nullptr;  // transposed k-space [W][nM+1][H]; measured k-space [W][H] (kout too)
   float *sched = nullptr, *lambda_dev = nullptr;
   float *xs = nullptr, *ys = nullptr, *ms = nullptr;  // solver-owned copies of the lattices
   uint16_t *shadow_img = nullptr, *shadow_mot = nullptr;  // fp16 shadows of the tables (cfg.table_fp16)
@@ -133,13 +134,15 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     return launch_motion_warp_fwd(s->image, s->o_mot, s->xs, s->ys, nM, H, W, s->t_mot, slot1, q);
                   }});
   }
-  st.push_back({"fft_fwd", [=](hipStream_t q) { return fft_exec_inplace(s->fftbuf, nM + 1, H, W, false, q); }});
+  // k-space lives transposed, [W][nM+1][H], between the two transforms (kspace.hip: 2 rocFFT kernels per
+  // transform instead of 4); b.kin and s->kout are [W][H] accordingly
+  st.push_back({"fft_fwd", [=](hipStream_t q) { return fft_fwd_to_transposed(s->fftbuf, s->fft_t, nM + 1, H, W, q); }});
   st.push_back({"select_dc_seed", [=](hipStream_t q) {
-                  return launch_select_dc_seed(s->fftbuf, b.col_group, b.kin, nM, H, W, s->kout, b.loss_hist,
-                                               s->iter_dev, q);
+                  return launch_select_dc_seed_t(s->fft_t, b.col_group, b.kin, nM, H, W, s->kout, b.loss_hist,
+                                                 s->iter_dev, q);
                 }});
   if (!backward) return st;
-  st.push_back({"fft_adjoint", [=](hipStream_t q) { return fft_exec_inplace(s->fftbuf, nM + 1, H, W, true, q); }});
+  st.push_back({"fft_adjoint", [=](hipStream_t q) { return fft_adj_from_transposed(s->fft_t, s->fftbuf, nM + 1, H, W, q); }});
   st.push_back({"image_grad_init_ge", [=](hipStream_t q) {
                   return launch_image_grad_init(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
                                                 b.loss_hist, s->dimage, q);
@@ -314,6 +317,8 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   A(fftbuf, 2 * s->P * (cfg->nM + 1))
   A(dimage, 2 * s->P)
   A(kout, 2 * s->P)
+  A(kin_t, 2 * s->P)
+  A(fft_t, 2 * s->P * (cfg->nM + 1))
   A(grad_img, s->n_params_img)
   // partial gradient tables of the motion grid: as many point ranges as it takes to bring one level slice
   // of dL/denc (8 B per point) down to ~2 MB per XCD L2 (csr.hip), at most 8: 320x320x10 -> 4, 640x640x20 -> 8
@@ -347,8 +352,9 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
     immoco_solver_destroy(s);
     return IMMOCO_E_HIP;
   }
-  // create the FFT plan now (rocFFT may compile kernels) so that solve() never does
-  if ((rc = fft_exec_inplace(s->fftbuf, cfg->nM + 1, cfg->H, cfg->W, false, s->stream))) {
+  // create the FFT plans now (rocFFT compiles kernels) so that solve() - and its stream capture - never does
+  if ((rc = fft_fwd_to_transposed(s->fftbuf, s->fft_t, cfg->nM + 1, cfg->H, cfg->W, s->stream)) ||
+      (rc = fft_adj_from_transposed(s->fft_t, s->fftbuf, cfg->nM + 1, cfg->H, cfg->W, s->stream))) {
     immoco_solver_destroy(s);
     return rc;
   }
@@ -363,7 +369,7 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   csr_plan_free(s->plan_img);
   csr_plan_free(s->plan_mot);
   float* bufs[] = {s->xs, s->ys, s->ms, s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
-                   s->kout,    s->grad_img, s->grad_mot, s->sched, s->lambda_dev};
+                   s->kout,    s->fft_t,    s->kin_t,    s->grad_img, s->grad_mot, s->sched, s->lambda_dev};
   for (float* b : bufs)
     if (b) hipFree(b);
   if (s->iter_dev) hipFree(s->iter_dev);
@@ -451,7 +457,8 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
 
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
-  Bind b{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
+  if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
+  Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
   std::vector<Step> steps = build_steps(s, b, true);
   s->graph_active = 0;
   if (s->cfg.use_graph) {
@@ -486,7 +493,7 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   }
   // tensors of the LAST forward pass (immoco.py:203-206)
   if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
-  if (out_kspace) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_kspace, s->kout, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
+  if (out_kspace && (rc = launch_transpose_c64(s->kout, out_kspace, s->cfg.W, s->cfg.H, q))) return rc;
   return leave(s, caller);
 }
 
@@ -538,7 +545,7 @@ extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group
   std::vector<Step> steps = build_steps(s, b, false);
   if ((rc = run_steps(steps, q))) return rc;
   if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
-  if (out_kspace) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_kspace, s->kout, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
+  if (out_kspace && (rc = launch_transpose_c64(s->kout, out_kspace, s->cfg.W, s->cfg.H, q))) return rc;
   return leave(s, caller);
 }
 
@@ -565,7 +572,8 @@ extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, 
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
-  Bind b{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, nullptr};
+  if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
+  Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, nullptr};
   std::vector<Step> steps = build_steps(s, b, true);
   const size_t n = steps.size();
   std::vector<hipEvent_t> ev((n + 1) * (size_t)reps);
