@@ -58,16 +58,15 @@ def algorithmic_bytes(solver, nM):
     }
 
 
-def cpu_baseline(iters_sample=2):
+def cpu_baseline(iters_sample=10):
     """The oracle (CPU restatement of the reference loop) on this box's host cores, config C2,
     a bounded sample of iterations; slices/s extrapolated to 3000 iterations."""
-    from oracle import immoco_oracle as orc
-    from miccai24_immoco_amd import synth
+    from oracle import immoco_oracle as orc, synth_cpu
     # torch's CPU kernels stop scaling (and then regress) far below the 256 hardware threads of the
     # GPU box: measured 38.7 s/iteration with 256 threads vs 7 s with 4; use at most 32
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    s = synth.make_slice(H, W, N_MOVEMENTS, 0)
+    s = synth_cpu.make_slice(H, W, N_MOVEMENTS, 0)
     masks = orc.extract_movement_groups(s["lines"], make_list=True)
     model = orc.OracleIMMoCo(masks)
     k = s["kspace"]

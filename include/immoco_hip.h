@@ -152,7 +152,9 @@ int immoco_affine_bicubic_bwd(const float* images, const float* theta, const flo
 /* ---- centred FFTs (src/utils/data_utils.py:29-34) over the last two dims.
  * mode 0: FFT  = fftshift(fftn(ifftshift(x)))   unnormalised
  * mode 1: IFFT = ifftshift(ifftn(fftshift(x)))  1/(HW)
- * mode 2: adjoint of mode 0 (= HW * IFFT), used by the backward pass.
+ * mode 2: adjoint of mode 0 (FFT's shifts around the unnormalised inverse transform; = HW * IFFT for even sizes)
+ * mode 3: adjoint of mode 1 (IFFT's shifts around the forward transform, / (HW); = FFT / (HW) for even sizes)
+ *         - both used by the backward passes; they differ from IFFT/FFT for odd sizes (different rolls).
  * in may equal out.  Plans are cached per (batch,H,W) inside the library. */
 int immoco_fft2c(const float* in, float* out, int32_t batch, int32_t H, int32_t W, int32_t mode,
                  void* stream);
@@ -285,7 +287,7 @@ int64_t immoco_solver_plan_entries(immoco_solver_t s, int32_t which);
  * footprint_bytes table (power of two), 4 in flight per lane.  Allocates and frees its own scratch.
  * ms_out: [host] average duration of one launch over `repeats` launches. */
 int immoco_probe_gather(int64_t footprint_bytes, int32_t bytes_per_load, int64_t n_lanes,
-                        int32_t loads_per_lane, int32_t repeats, hipStream_t stream, float* ms_out);
+                        int32_t loads_per_lane, int32_t repeats, void* stream, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "kernels.hpp"
@@ -86,11 +87,12 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
   for (int d = 0; d < D; ++d) pos_fract(ax.a[d][li[d]], scale, cell[d], fr[d]);
   const uint32_t part = (uint32_t)(p / part_size);
   const uint32_t p_rel = (uint32_t)(p - (int64_t)part * part_size);
+  constexpr int NPAIR = 1 << (D - 1);
+  uint32_t idx[NPAIR][2];
+  float w[NPAIR][2], wrest[NPAIR];  // wrest: product of the factors of dimensions >= 1 (shared by the two dim-0 corners)
+  bool live[NPAIR];
 #pragma unroll
-  for (int pair = 0; pair < (1 << (D - 1)); ++pair) {
-    uint32_t idx[2];
-    float w[2];
-    float wrest = 1.0f;  // product of the factors of dimensions >= 1 (shared by the two dim-0 corners)
+  for (int pair = 0; pair < NPAIR; ++pair) {
 #pragma unroll
     for (int b0 = 0; b0 < 2; ++b0) {
       const int corner = 2 * pair + b0;
@@ -104,30 +106,51 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
         wc *= f;
         if (d > 0) wr *= f;
       }
-      idx[b0] = grid_index<D>(cc, size, res, hashed, pow2);
-      w[b0] = wc;
-      wrest = wr;
+      idx[pair][b0] = grid_index<D>(cc, size, res, hashed, pow2);
+      w[pair][b0] = wc;
+      wrest[pair] = wr;
     }
-    const uint32_t kbase = lv.offset[l] * (uint32_t)n_parts + part * size;  // counters ordered by (level, part, slot)
-    if (pair_merge && (idx[0] ^ idx[1]) == 1u) {
+    live[pair] = true;
+  }
+  // Corners of ONE point that land in the same slot are folded into one entry (weights summed).  This is
+  // what makes the wrapped-stride levels cheap (levels 12-15 of the reference's grids, hashgrid.hip
+  // build_levels: their index ignores the trailing dimensions, so 2 or 4 corner pairs coincide); on
+  // ordinary levels nothing coincides and the entries are unchanged.
+#pragma unroll
+  for (int a = 1; a < NPAIR; ++a) {
+#pragma unroll
+    for (int b = 0; b < a; ++b) {
+      if (live[a] && live[b] && idx[a][0] == idx[b][0] && idx[a][1] == idx[b][1]) {
+        w[b][0] += w[a][0];
+        w[b][1] += w[a][1];
+        wrest[b] += wrest[a];
+        live[a] = false;
+      }
+    }
+  }
+  const uint32_t kbase = lv.offset[l] * (uint32_t)n_parts + part * size;  // counters ordered by (level, part, slot)
+#pragma unroll
+  for (int pair = 0; pair < NPAIR; ++pair) {
+    if (!live[pair]) continue;
+    if (pair_merge && (idx[pair][0] ^ idx[pair][1]) == 1u) {
       // twin entry: both dim-0 corners of this point land in ONE aligned slot pair (see hashgrid.hip).
       // Stored once at the even slot: slot LSB = 1 when the even slot belongs to the HIGH dim-0 corner,
       // weight = -(product of the other dimensions' factors); the dim-0 fraction comes from a per-level
       // table at run time.  One dL/denc gather then serves two slots.
-      const uint32_t even = idx[0] & ~1u, swap = idx[0] & 1u;
+      const uint32_t even = idx[pair][0] & ~1u, swap = idx[pair][0] & 1u;
       const uint32_t key = kbase + even;
       const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
       if (FILL)
         entries[offs[key] + pos] = make_uint2((p_rel << SLOT_BITS) | (even & (SLOTS_PER_ITEM - 1)) | swap,
-                                              __float_as_uint(wrest) | 0x80000000u);
+                                              __float_as_uint(wrest[pair]) | 0x80000000u);
     } else {
 #pragma unroll
       for (int b0 = 0; b0 < 2; ++b0) {
-        const uint32_t key = kbase + idx[b0];
+        const uint32_t key = kbase + idx[pair][b0];
         const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
         if (FILL)
           entries[offs[key] + pos] =
-              make_uint2((p_rel << SLOT_BITS) | (idx[b0] & (SLOTS_PER_ITEM - 1)), __float_as_uint(w[b0]));
+              make_uint2((p_rel << SLOT_BITS) | (idx[pair][b0] & (SLOTS_PER_ITEM - 1)), __float_as_uint(w[pair][b0]));
       }
     }
   }
@@ -316,7 +339,11 @@ struct CsrPlan {
   uint32_t n_items = 0;
   uint64_t n_entries = 0;
   int64_t bytes = 0;
-  uint32_t shared_slot_end = 0;  // slots < this may belong to "shared" (atomic-flush) items
+  // slot blocks that receive any gradient, merged over the parts: {first slot, n slots | shared << 31}.
+  // shared: some item flushes into the block with atomics, so the consumer (Adam) has to clear it.  Blocks
+  // that are not listed never receive a gradient: their Adam update is exactly zero and is skipped.
+  uint2* touched = nullptr;
+  uint32_t n_touched = 0;
   bool pair_merge = false;       // twin entries present (3-D grids with <= 256 dim-0 lattice values)
   float* f0tab = nullptr;        // [n_levels][axn[0]] dim-0 fractions for the twin entries
 };
@@ -326,6 +353,7 @@ void csr_plan_free(CsrPlan* p) {
   if (p->entries) hipFree(p->entries);
   if (p->items) hipFree(p->items);
   if (p->f0tab) hipFree(p->f0tab);
+  if (p->touched) hipFree(p->touched);
   delete p;
 }
 
@@ -367,9 +395,8 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   IMMOCO_CHECK_HIP(hipMemcpyAsync(h_offs.data(), offs, h_offs.size() * 4, hipMemcpyDeviceToHost, st));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(st));
   pl->n_entries = h_offs[n_cnt];
-  IMMOCO_REQUIRE(pl->pair_merge ? pl->n_entries <= (uint64_t)n * lv.n_levels * (1u << D)
-                                : pl->n_entries == (uint64_t)n * lv.n_levels * (1u << D),
-                 "csr plan: entry count mismatch");
+  // (twin entries and same-slot folding only ever remove entries)
+  IMMOCO_REQUIRE(pl->n_entries <= (uint64_t)n * lv.n_levels * (1u << D), "csr plan: entry count mismatch");
   uint2* sorted = nullptr;  // slot-sorted build array, permuted into the final layout below
   IMMOCO_CHECK_HIP(hipMalloc((void**)&sorted, (size_t)pl->n_entries * 8));
   IMMOCO_CHECK_HIP(hipMemsetAsync(counts, 0, (n_cnt + 1) * 4, st));
@@ -380,6 +407,7 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   // with more than ENTRIES_PER_ITEM entries (coarse dense levels) is split by entries over several
   // items, which then flush with atomics ("shared").
   std::vector<std::vector<BwdItem>> per_part(NP);
+  std::map<uint32_t, uint32_t> touched;  // first slot of a block -> n slots | shared << 31
   for (int l = 0; l < lv.n_levels; ++l) {
     for (int q = 0; q < NP; ++q) {
       const size_t cb = (size_t)lv.offset[l] * NP + (size_t)q * lv.size[l];  // counter index of slot 0
@@ -387,16 +415,27 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
         const uint32_t ns = std::min<uint32_t>(SLOTS_PER_ITEM, lv.size[l] - s);
         const uint32_t e0 = h_offs[cb + s], e1 = h_offs[cb + s + ns];
         if (e1 == e0) continue;
+        uint32_t& tb = touched[lv.offset[l] + s];
+        tb |= ns;
+        if (e1 - e0 > (uint32_t)ENTRIES_PER_ITEM) tb |= 0x80000000u;
         if (e1 - e0 <= (uint32_t)ENTRIES_PER_ITEM) {
           per_part[q].push_back({e0, e1, lv.offset[l] + s, ns, (uint32_t)l, (uint32_t)q, 0u, 0u});
         } else {
           for (uint32_t e = e0; e < e1; e += ENTRIES_PER_ITEM)
             per_part[q].push_back({e, std::min<uint32_t>(e + ENTRIES_PER_ITEM, e1), lv.offset[l] + s, ns, (uint32_t)l,
                                    (uint32_t)q | (1u << 16), 0u, 0u});
-          pl->shared_slot_end = std::max(pl->shared_slot_end, lv.offset[l] + s + ns);
         }
       }
     }
+  }
+  {
+    std::vector<uint2> tv;
+    tv.reserve(touched.size());
+    for (const auto& kv : touched) tv.push_back(make_uint2(kv.first, kv.second));
+    pl->n_touched = (uint32_t)tv.size();
+    IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->touched, std::max<size_t>(1, tv.size()) * sizeof(uint2)));
+    IMMOCO_CHECK_HIP(hipMemcpyAsync(pl->touched, tv.data(), tv.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+    IMMOCO_CHECK_HIP(hipStreamSynchronize(st));  // tv goes out of scope
   }
   // XCD-aware interleave: workgroup i runs on XCD i % 8 (observed round-robin dispatch; a different
   // placement only costs speed).  XCD x serves part x % NP; the 8/NP XCDs of a part alternate over
@@ -478,7 +517,10 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
 int64_t csr_plan_bytes(const CsrPlan* p) { return p ? p->bytes : 0; }
 int64_t csr_plan_entries(const CsrPlan* p) { return p ? (int64_t)p->n_entries : 0; }
 int csr_plan_parts(const CsrPlan* p) { return p ? p->n_parts : 1; }
-uint32_t csr_plan_shared_slot_end(const CsrPlan* p) { return p ? p->shared_slot_end : 0; }
+const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n) {
+  *n = p ? p->n_touched : 0;
+  return p ? p->touched : nullptr;
+}
 
 // dtable: n_parts partial tables, `part_stride` floats apart.  zeroed != 0: the caller guarantees
 // that the buffers hold zeros or stale values of the same plan (plain stores); otherwise the

@@ -36,7 +36,11 @@ int build_levels(const immoco_grid_cfg* cfg, Levels* out) {
     n = (n + 7) / 8 * 8;
     uint64_t cap = 1ull << cfg->log2_hashmap_size;
     if (n > cap) n = cap;
-    uint64_t stride = 1;  // grid_index(): stride after the dense walk
+    // grid_index(): stride after the dense walk, in uint32 like upstream - the product WRAPS.  For the
+    // reference's config (base 16, scale 2: power-of-two resolutions) res*res wraps to exactly 0 from
+    // res = 2^16 (level 12) on, so `hashmap_size < stride` is false there and levels 12-15 of both grids
+    // use the dense wrapped index (c0 + c1*res) % size, not the prime hash (matches device grid_index()).
+    uint32_t stride = 1;
     for (int d = 0; d < cfg->dims; ++d) {
       if (stride > n) break;
       stride *= res;

@@ -84,6 +84,13 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float s
 int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n,
                       int64_t zero_limit, const float* sched, const int32_t* iter_dev, float beta1, float beta2,
                       float eps, hipStream_t st, void* shadow = nullptr, int64_t shadow_begin = 0);
+// touched-blocks variant (transposed-index plans): the first n_w parameters (MLP weights) and the listed
+// slot blocks of the table behind them are updated; everything else has g = m = v = 0 for ever, i.e. an
+// exactly-zero Adam update, and is skipped.  Gradients of the weights and of shared blocks
+// are cleared after use.
+int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n_w,
+                       const uint2* blocks, uint32_t n_blocks, const float* sched, const int32_t* iter_dev,
+                       float beta1, float beta2, float eps, hipStream_t st, void* shadow = nullptr);
 
 // csr.hip — atomic-free hash-grid backward for fixed lattices
 struct CsrPlan;
@@ -93,7 +100,9 @@ void csr_plan_free(CsrPlan* p);
 int64_t csr_plan_bytes(const CsrPlan* p);
 int64_t csr_plan_entries(const CsrPlan* p);
 int csr_plan_parts(const CsrPlan* p);
-uint32_t csr_plan_shared_slot_end(const CsrPlan* p);  // table slots below this need zeroing by the consumer
+// slot blocks that receive gradients: {first slot, n slots | shared << 31} (device array); shared blocks are
+// flushed with atomics and have to be cleared by the consumer, unlisted blocks never get a gradient
+const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n);
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,
                    int zeroed, hipStream_t st);
 

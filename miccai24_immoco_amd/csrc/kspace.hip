@@ -98,7 +98,13 @@ int get_split_plans(int B, int H, int W, SplitPlans* out) {
   return IMMOCO_OK;
 }
 
+// Plans are cached process-wide and shared by all solver handles (several same-shape slices may be in flight
+// from different host threads, ctypes releases the GIL): SetStream + Exec on a shared handle is one critical
+// section, otherwise another thread's SetStream could land between the two and the transform would be
+// enqueued - or captured - on the wrong stream.  (The 1-D plans used here need no rocFFT work buffer.)
+std::mutex g_exec_mu;
 int exec_c2c(hipfftHandle plan, float* in, float* out, int dir, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_exec_mu);
   hipfftResult r = hipfftSetStream(plan, st);
   if (r == HIPFFT_SUCCESS) r = hipfftExecC2C(plan, (hipfftComplex*)in, (hipfftComplex*)out, dir);
   if (r != HIPFFT_SUCCESS) {
@@ -191,8 +197,11 @@ int get_tmp(size_t bytes, void** out) {
 int fft2c(const float* in, float* out, int batch, int H, int W, int mode, hipStream_t st) {
   const int64_t n = (int64_t)batch * H * W;
   if (n == 0) return IMMOCO_OK;
-  const bool inverse = mode != 0;
-  const float norm = mode == 1 ? 1.0f / ((float)H * (float)W) : 1.0f;
+  // mode 0: FFT; 1: IFFT; 2: adjoint of FFT (FFT's shifts around the unnormalised inverse transform);
+  // 3: adjoint of IFFT (IFFT's shifts around the forward transform, / (H*W)).  For even sizes both shifts are
+  // the same roll and 2 / 3 coincide with IFFT*(HW) / FFT/(HW); for odd sizes they do not.
+  const bool inverse = mode == 1 || mode == 2;
+  const float norm = (mode == 1 || mode == 3) ? 1.0f / ((float)H * (float)W) : 1.0f;
   int rc;
   if ((H % 2) == 0 && (W % 2) == 0) {
     // even sizes: checkerboard signs replace both rolls
@@ -207,7 +216,7 @@ int fft2c(const float* in, float* out, int batch, int H, int W, int mode, hipStr
   if ((rc = get_tmp((size_t)n * 8, &tmp))) return rc;
   // (mode 2, the adjoint of mode 0, keeps mode 0's shifts around the inverse transform.)
   const int hr = H / 2, hc = W / 2;
-  const bool ifft_shifts = mode == 1;
+  const bool ifft_shifts = mode == 1 || mode == 3;
   const int pre_r = ifft_shifts ? hr : (H - hr) % H, pre_c = ifft_shifts ? hc : (W - hc) % W;
   const int post_r = ifft_shifts ? (H - hr) % H : hr, post_c = ifft_shifts ? (W - hc) % W : hc;
   if ((rc = launch_roll(in, (float*)tmp, n, H, W, pre_r, pre_c, 1.0f, 0, st))) return rc;
@@ -526,7 +535,7 @@ using namespace immoco;
 extern "C" int immoco_fft2c(const float* in, float* out, int32_t batch, int32_t H, int32_t W, int32_t mode,
                             void* stream) {
   IMMOCO_REQUIRE(batch >= 0 && H > 0 && W > 0, "fft2c: bad shape batch=%d H=%d W=%d", batch, H, W);
-  IMMOCO_REQUIRE(mode >= 0 && mode <= 2, "fft2c: bad mode %d", mode);
+  IMMOCO_REQUIRE(mode >= 0 && mode <= 3, "fft2c: bad mode %d", mode);
   IMMOCO_REQUIRE(batch == 0 || (in && out), "fft2c: NULL buffer");
   return fft2c(in, out, batch, H, W, mode, as_stream(stream));
 }

@@ -73,6 +73,61 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+// Touched-blocks Adam: workgroup b < n_wblocks handles 1024 float4 of the MLP weights, the others one slot
+// block (<= 2048 slots = 1024 float4) of the table.  Table slots outside the listed blocks never receive a
+// gradient (the block list is a constant of the lattice, csr.hip), so g = m = v = 0 there for ever and
+// torch's update is exactly 0: skipping them is the "touched-only Adam" of SURVEY a14.
+__global__ __launch_bounds__(256) void adam_blocks_kernel(float* __restrict__ p, float* __restrict__ g, int n_gparts,
+                                                          int64_t g_stride, float* __restrict__ m,
+                                                          float* __restrict__ v, int64_t n_w4, uint32_t n_wblocks,
+                                                          const uint2* __restrict__ blocks,
+                                                          const float* __restrict__ sched,
+                                                          const int32_t* __restrict__ iter_dev, float b1, float b2,
+                                                          float eps, __half* __restrict__ shadow) {
+  const int it = *iter_dev;
+  const float step_size = sched[2 * it], bc2_sqrt = sched[2 * it + 1];
+  int64_t i0, cnt;
+  bool zero;
+  if (blockIdx.x < n_wblocks) {
+    i0 = (int64_t)blockIdx.x * 1024;
+    cnt = n_w4 - i0 < 1024 ? n_w4 - i0 : 1024;
+    zero = true;
+  } else {
+    const uint2 b = blocks[blockIdx.x - n_wblocks];
+    i0 = n_w4 + (int64_t)b.x / 2;            // 2 floats per slot, 4 per float4
+    cnt = (b.y & 0x7FFFFFFFu) / 2;
+    zero = b.y >> 31;
+  }
+  for (int64_t k = threadIdx.x; k < cnt; k += 256) {
+    const int64_t i = i0 + k;
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    for (int q = 1; q < n_gparts; ++q) {
+      const float4 gq = reinterpret_cast<const float4*>(g + q * g_stride)[i];
+      gg.x += gq.x;
+      gg.y += gq.y;
+      gg.z += gq.z;
+      gg.w += gq.w;
+    }
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, step_size, bc2_sqrt, b1, b2, eps);
+    adam_one(pp.y, gg.y, mm.y, vv.y, step_size, bc2_sqrt, b1, b2, eps);
+    adam_one(pp.z, gg.z, mm.z, vv.z, step_size, bc2_sqrt, b1, b2, eps);
+    adam_one(pp.w, gg.w, mm.w, vv.w, step_size, bc2_sqrt, b1, b2, eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    if (shadow && i >= n_w4) {
+      __half2* sh = reinterpret_cast<__half2*>(shadow + 4 * (i - n_w4));
+      sh[0] = __floats2half2_rn(pp.x, pp.y);
+      sh[1] = __floats2half2_rn(pp.z, pp.w);
+    }
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (zero)
+      for (int q = 0; q < n_gparts; ++q) reinterpret_cast<float4*>(g + q * g_stride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 static unsigned adam_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4 + 1, 256), 2048)); }
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
@@ -96,6 +151,22 @@ int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float*
                      ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
   adam_kernel<true><<<adam_grid(n), 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n, zero_limit, 0.f, 1.f, sched, iter_dev, beta1,
                                                   beta2, eps, reinterpret_cast<__half*>(shadow), shadow_begin);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n_w,
+                       const uint2* blocks, uint32_t n_blocks, const float* sched, const int32_t* iter_dev,
+                       float beta1, float beta2, float eps, hipStream_t st, void* shadow) {
+  IMMOCO_REQUIRE((n_w % 4) == 0, "adam: the MLP weight count must be a multiple of 4 (got %lld)", (long long)n_w);
+  IMMOCO_REQUIRE(n_gparts >= 1 && (g_stride % 4) == 0, "adam: partial gradient stride must be a multiple of 4");
+  IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0, "adam: buffers must be 16-byte aligned");
+  const uint32_t n_wblocks = (uint32_t)cdiv(n_w / 4, 1024);
+  if (n_wblocks + n_blocks == 0) return IMMOCO_OK;
+  adam_blocks_kernel<<<n_wblocks + n_blocks, 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n_w / 4, n_wblocks, blocks,
+                                                          sched, iter_dev, beta1, beta2, eps,
+                                                          reinterpret_cast<__half*>(shadow));
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const V* __restrict__
 using namespace immoco;
 
 extern "C" int immoco_probe_gather(int64_t footprint_bytes, int32_t bytes_per_load, int64_t n_lanes,
-                                   int32_t loads_per_lane, int32_t repeats, hipStream_t st, float* ms_out) {
+                                   int32_t loads_per_lane, int32_t repeats, void* stream, float* ms_out) {
+  hipStream_t st = as_stream(stream);
   IMMOCO_REQUIRE(ms_out != nullptr, "ms_out is NULL");
   IMMOCO_REQUIRE(bytes_per_load == 8 || bytes_per_load == 16, "bytes_per_load must be 8 or 16");
   IMMOCO_REQUIRE(footprint_bytes >= 4096 && (footprint_bytes & (footprint_bytes - 1)) == 0,

@@ -173,21 +173,33 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // optimizer param-group order of the reference: motion first, then image (immoco.py:149-154)
   if (nM > 0)
     st.push_back({"adam_motion", [=](hipStream_t q) {
-                    // with a plan only the MLP weights and the (coarse) slots that are flushed by
-                    // atomics need clearing; everything else is overwritten by csr_bwd_kernel
-                    const int64_t zl = s->plan_mot ? ((s->n_w_mot + 2 * (int64_t)csr_plan_shared_slot_end(s->plan_mot) + 3) / 4 * 4)
-                                                   : s->n_params_mot;
-                    return launch_adam_sched(b.p_mot, s->grad_mot, s->plan_mot ? s->mot_parts : 1, s->mot_gstride,
-                                             b.a_mot, b.a_mot + s->n_params_mot, s->n_params_mot, zl, s->sched,
+                    // with a plan only the MLP weights and the slot blocks that receive gradients are visited
+                    // (everything else has an exactly-zero update), and only the weights and the blocks that
+                    // are flushed by atomics need clearing; the rest is overwritten by csr_bwd_kernel
+                    if (s->plan_mot) {
+                      uint32_t nb = 0;
+                      const uint2* blocks = csr_plan_touched(s->plan_mot, &nb);
+                      return launch_adam_blocks(b.p_mot, s->grad_mot, s->mot_parts, s->mot_gstride, b.a_mot,
+                                                b.a_mot + s->n_params_mot, s->n_w_mot, blocks, nb, s->sched,
+                                                s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
+                                                s->cfg.table_fp16 ? s->shadow_mot : nullptr);
+                    }
+                    return launch_adam_sched(b.p_mot, s->grad_mot, 1, s->mot_gstride, b.a_mot,
+                                             b.a_mot + s->n_params_mot, s->n_params_mot, s->n_params_mot, s->sched,
                                              s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
                                              s->cfg.table_fp16 ? s->shadow_mot : nullptr, s->n_w_mot);
                   }, 1});
   st.push_back({"adam_image", [=](hipStream_t q) {
-                  const int64_t zl = s->plan_img ? ((s->n_w_img + 2 * (int64_t)csr_plan_shared_slot_end(s->plan_img) + 3) / 4 * 4)
-                                                 : s->n_params_img;
+                  if (s->plan_img) {
+                    uint32_t nb = 0;
+                    const uint2* blocks = csr_plan_touched(s->plan_img, &nb);
+                    return launch_adam_blocks(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
+                                              s->n_w_img, blocks, nb, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
+                                              s->cfg.table_fp16 ? s->shadow_img : nullptr);
+                  }
                   return launch_adam_sched(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
-                                           s->n_params_img, zl, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
-                                           s->cfg.table_fp16 ? s->shadow_img : nullptr, s->n_w_img);
+                                           s->n_params_img, s->n_params_img, s->sched, s->iter_dev, 0.9f, 0.999f,
+                                           1e-8f, q, s->cfg.table_fp16 ? s->shadow_img : nullptr, s->n_w_img);
                 }, 2});
   st.push_back({"tick", [=](hipStream_t q) {
                   tick_kernel<<<1, 1, 0, q>>>(s->iter_dev);

@@ -54,9 +54,12 @@ def solve_sharded(n_slices: int, solve_fn: Callable[[int], torch.Tensor], group=
     and the final images are gathered once."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    # decided identically on EVERY rank before anything is solved: a rank with an empty block would not know
+    # the image shape for the collective, and raising on that rank alone would leave the others waiting in
+    # all_gather until the RCCL timeout
+    if n_slices < world:
+        raise ValueError(f"solve_sharded: {n_slices} slices for {world} ranks - every rank needs at least one slice")
     a, b = shard_range(n_slices, rank, world)
     imgs: List[torch.Tensor] = [solve_fn(i) for i in range(a, b)]
-    if not imgs:
-        raise RuntimeError("rank without slices: use n_slices >= world size")
     local = torch.stack(imgs)
     return gather_images(local, n_slices, group=group, dst=dst)

@@ -6,6 +6,13 @@ single flat fp32 ``params`` Parameter ([W1 | W2(padded) | hash table], tcnn
 order), ``forward(x[N, n_in]) -> [N, n_out]``.  Differences, by design: compute
 and output are fp32 (tcnn: fp16 with loss scale 128), and the initial values
 come from the library's counter-based generator instead of tcnn's RNG stream.
+
+Backward of the encoding: the reference always passes the same lattice tensor
+(``identy_grid.view(-1, 2)`` / ``input_grid``, immoco.py:72-80,85,93).  When the
+input IS such a lattice (checked exactly, once per tensor), the module builds the
+transposed index of the C-ABI (``immoco_grid_plan_*``) and every backward is the
+atomic-free gather of csrc/csr.hip; any other input uses the generic atomic scatter
+(``immoco_hashgrid_bwd``), which is ~20x slower at the reference's sizes.
 """
 from __future__ import annotations
 
@@ -16,21 +23,81 @@ import torch
 from . import _lib as L
 
 
+def _detect_lattice(x: torch.Tensor):
+    """x [N, D] -> (nM, H, W, axes) when x is exactly the row-major lattice the reference builds
+    (D = 3: make_grids((nM, H, W)) columns (m, row, col); D = 2: identy_grid.view(-1, 2) columns
+    (x = col, y = row)), else None.  A handful of small device ops and one host sync, done once per tensor."""
+    n, d = x.shape
+    if n == 0 or d not in (2, 3):
+        return None
+    if d == 3:
+        m, r, c = x[:, 0], x[:, 1], x[:, 2]
+        same_m = m == m[0]
+        hw = int(same_m.sum())                       # leading block with the first m
+        if hw == 0 or n % hw or not bool(same_m[:hw].all()):
+            return None
+        w = int((r[:hw] == r[0]).sum())
+        if w == 0 or hw % w or not bool((r[:w] == r[0]).all()):
+            return None
+        nM, H, W = n // hw, hw // w, w
+        a0, a1, a2 = m[::hw].contiguous(), r[:hw:w].contiguous(), c[:W].contiguous()
+        ref = torch.stack(torch.meshgrid(a0, a1, a2, indexing="ij"), dim=-1).view(-1, 3)
+        axes = (a0, a1, a2)
+    else:
+        cx, ry = x[:, 0], x[:, 1]
+        w = int((ry == ry[0]).sum())
+        if w == 0 or n % w or not bool((ry[:w] == ry[0]).all()):
+            return None
+        nM, H, W = 1, n // w, w
+        a0, a1 = cx[:W].contiguous(), ry[::W].contiguous()
+        yy, xx = torch.meshgrid(a1, a0, indexing="ij")
+        ref = torch.stack([xx, yy], dim=-1).view(-1, 2)
+        axes = (a0, a1, a0)
+    if not torch.equal(ref, x):
+        return None
+    return nM, H, W, axes
+
+
+class _GridPlan:
+    """RAII wrapper of immoco_grid_plan_t (transposed index of one lattice)."""
+
+    def __init__(self, grid_cfg, nM, H, W, axes):
+        self.handle = C.c_void_p()
+        self.axes = axes  # keep the device arrays alive while the plan is built
+        L.check(L.lib().immoco_grid_plan_create(C.byref(grid_cfg), nM, H, W, L.ptr(axes[0]), L.ptr(axes[1]),
+                                                L.ptr(axes[2]), C.byref(self.handle), L.stream_ptr()),
+                "grid_plan_create")
+
+    def close(self):
+        if self.handle:
+            L.lib().immoco_grid_plan_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _INRFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, params, mod):
         L.require_gpu(x, params, what="NetworkWithInputEncoding")
+        key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)   # of the caller's tensor
         x = x.contiguous().float()
         n = x.shape[0]
         w1, w2, tab = mod._split(params)
-        enc = torch.empty((n, 32), device=x.device, dtype=torch.float32)
+        # level-major encoding [L][n][2]: a wave's accesses to one level are contiguous (solver layout)
+        enc = torch.empty((mod.grid_cfg.n_levels, n, 2), device=x.device, dtype=torch.float32)
         out = torch.empty((n, 2), device=x.device, dtype=torch.float32)
         lib, st = L.lib(), L.stream_ptr()
-        L.check(lib.immoco_hashgrid_fwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(tab), L.ptr(enc), 32, 2, st),
+        L.check(lib.immoco_hashgrid_fwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(tab), L.ptr(enc), 2, 2 * n, st),
                 "hashgrid_fwd")
-        L.check(lib.immoco_mlp_fwd(C.byref(mod.mlp_cfg), L.ptr(enc), 32, 2, n, L.ptr(w1), L.ptr(w2), L.ptr(out), st),
+        L.check(lib.immoco_mlp_fwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(out), st),
                 "mlp_fwd")
         ctx.mod = mod
+        ctx.plan = mod._plan_for(x, key)
         ctx.save_for_backward(x, params, enc)
         return out
 
@@ -45,15 +112,19 @@ class _INRFunction(torch.autograd.Function):
         dw1, dw2, dtab = mod._split(dparams)
         denc = torch.empty_like(enc)
         lib, st = L.lib(), L.stream_ptr()
-        L.check(lib.immoco_mlp_bwd(C.byref(mod.mlp_cfg), L.ptr(enc), 32, 2, n, L.ptr(w1), L.ptr(w2), L.ptr(dout),
+        L.check(lib.immoco_mlp_bwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(dout),
                                    L.ptr(denc), L.ptr(dw1), L.ptr(dw2), st), "mlp_bwd")
-        L.check(lib.immoco_hashgrid_bwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(denc), 32, 2, L.ptr(dtab), st),
-                "hashgrid_bwd")
+        if ctx.plan is not None:
+            L.check(lib.immoco_grid_plan_bwd(ctx.plan.handle, L.ptr(denc), L.ptr(dtab), st), "grid_plan_bwd")
+        else:
+            L.check(lib.immoco_hashgrid_bwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(denc), 2, 2 * n, L.ptr(dtab), st),
+                    "hashgrid_bwd")
         return None, dparams, None
 
 
 class NetworkWithInputEncoding(torch.nn.Module):
-    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, device="cuda"):
+    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, device="cuda",
+                 lattice_plans=True):
         super().__init__()
         if n_output_dims != 2:
             raise L.ImmocoError("only n_output_dims=2 is supported (the reference's INRs)")
@@ -73,10 +144,31 @@ class NetworkWithInputEncoding(torch.nn.Module):
             L.check(L.lib().immoco_init_params(C.byref(self.grid_cfg), C.byref(self.mlp_cfg), seed & 0xFFFFFFFF,
                                                L.ptr(p), L.stream_ptr()), "init_params")
         self.params = torch.nn.Parameter(p)
+        # transposed index of the last lattice input, keyed like the oracle's plan cache
+        # (oracle/immoco_oracle.py:OracleINR.plan_for): storage address, shape and in-place version
+        self.lattice_plans = lattice_plans
+        self._plan = None
+        self._plan_key = None
 
     def _split(self, p):
         a, b = self.n_w1, self.n_w1 + self.n_w2
         return p[:a], p[a:b], p[b:]
+
+    def _plan_for(self, x, key):
+        """The cached immoco_grid_plan of input tensor x (identified by `key`), or None when x is not a lattice."""
+        if not self.lattice_plans:
+            return None
+        if key != self._plan_key:
+            # (the old plan is freed when the last autograd context that still points at it is gone)
+            self._plan, self._plan_key = None, key
+            lat = _detect_lattice(x)
+            if lat is not None:
+                try:
+                    with torch.cuda.device(x.device):
+                        self._plan = _GridPlan(self.grid_cfg, *lat)
+                except L.ImmocoError:
+                    self._plan = None       # lattice too large for one part of the index: generic scatter
+        return self._plan
 
     def forward(self, x):
         return _INRFunction.apply(x, self.params, self)

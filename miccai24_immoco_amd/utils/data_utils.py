@@ -23,7 +23,8 @@ def _fft2c(x: torch.Tensor, mode: int) -> torch.Tensor:
 
 
 class _CenteredFFT(torch.autograd.Function):
-    """mode 0: FFT (adjoint = mode 2); mode 1: IFFT (adjoint = FFT / (HW))."""
+    """mode 0: FFT (adjoint = mode 2); mode 1: IFFT (adjoint = mode 3: the IFFT's own shifts around the
+    forward transform, / (HW) - equal to FFT / (HW) for even sizes only)."""
 
     @staticmethod
     def forward(ctx, x, mode):
@@ -34,8 +35,7 @@ class _CenteredFFT(torch.autograd.Function):
     def backward(ctx, g):
         if ctx.mode == 0:
             return _fft2c(g, 2), None
-        H, W = g.shape[-2:]
-        return _fft2c(g, 0) / (H * W), None
+        return _fft2c(g, 3), None
 
 
 def FFT(x):

@@ -80,6 +80,37 @@ def test_calmetric2d_and_3d_consistency():
     assert abs(float(rec["psnr"]) - p2) <= 1e-5
 
 
+def _check_product_metrics_vs_reference_golden(g, dev):
+    """The PRODUCT functions behind bench.py's psnr_db (utils/evaluate.py: normalize / my_psnr / rmse /
+    crop_psnr) against vectors produced by the reference's own src/utils/evaluate.py:19-47
+    (tools/gen_golden.py -> tests/golden/ops.npz)."""
+    a, b = torch.from_numpy(g["metric_a"]).to(dev), torch.from_numpy(g["metric_b"]).to(dev)
+    na, nb = E.normalize(a), E.normalize(b)
+    np.testing.assert_allclose(na.cpu().numpy(), g["normalize_a"], rtol=1e-6, atol=1e-7)
+    assert abs(float(E.my_psnr(na, nb, data_range=1.0)) - float(g["psnr_ab"])) <= 1e-4
+    assert abs(float(E.rmse(na, nb)) - float(g["rmse_ab"])) <= 1e-6
+    # batch branch of normalize (evaluate.py:20-26) and data_range=None (peak of img2)
+    ab = torch.cat([a, b * 2 + 1])
+    nab = E.normalize(ab)
+    np.testing.assert_allclose(nab[0:1].cpu().numpy(), g["normalize_a"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(nab[1:2].cpu().numpy(), nb.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(float(E.my_psnr(na, nb)) - float(g["psnr_ab"]) - 20 * np.log10(float(nb.max()))) <= 1e-4
+    # crop_psnr == the same chain on the centre-half crop (test_immoco.py:77-81)
+    x, y = a[0, 0], b[0, 0]
+    c = x.shape[0] // 4
+    exp = float(E.my_psnr(E.normalize(x[c:-c, c:-c][None, None]), E.normalize(y[c:-c, c:-c][None, None]), data_range=1.0))
+    assert abs(E.crop_psnr(x, y) - exp) <= 1e-6
+
+
+def test_product_psnr_rmse_normalize_vs_reference_golden(golden):
+    _check_product_metrics_vs_reference_golden(golden("ops"), "cpu")
+
+
+@pytest.mark.gpu
+def test_product_psnr_rmse_normalize_vs_reference_golden_on_device(golden):
+    _check_product_metrics_vs_reference_golden(golden("ops"), "cuda")
+
+
 @pytest.mark.gpu
 def test_metrics_on_device_match_cpu():
     a, b = _pair(160, 160, seed=6)

@@ -11,11 +11,13 @@ def test_level_geometry_2d_3d():
     assert g2.resolutions[:7] == [16, 32, 64, 128, 256, 512, 1024]
     assert g2.sizes[:6] == [256, 1024, 4096, 16384, 65536, 262144] and set(g2.sizes[6:]) == {524288}
     assert g2.offsets[:7] == [0, 256, 1280, 5376, 21760, 87296, 349440]
-    assert g2.hashed == [False] * 6 + [True] * 10
+    # levels 12-15 (res >= 2^16): upstream's uint32 `stride *= resolution` wraps to 0, so `hashmap_size < stride`
+    # is false and the level keeps the dense (wrapped) index - see test_wrapped_stride_levels_known_answers
+    assert g2.hashed == [False] * 6 + [True] * 6 + [False] * 4
     assert g2.n_entries == 5592320
     g3 = orc.geometry_from_config(3, orc.encoding_config)
     assert g3.sizes[:3] == [4096, 32768, 262144] and g3.offsets[:4] == [0, 4096, 36864, 299008]
-    assert g3.hashed == [False] * 3 + [True] * 13
+    assert g3.hashed == [False] * 3 + [True] * 9 + [False] * 4
     assert g3.n_entries == 7114752
     assert [s for s in g3.scales[:3]] == [15.0, 31.0, 63.0]
     # parameter counts quoted in SURVEY a5/a6
@@ -38,6 +40,42 @@ def test_hash_known_answers():
         exp.append(h % 524288)
     assert orc.grid_index(cell, g3, lvl).tolist() == exp
     assert exp[0] == ((1 ^ ((2 * 2654435761) & 0xFFFFFFFF) ^ ((3 * 805459861) & 0xFFFFFFFF)) % 524288)
+
+
+def test_wrapped_stride_levels_known_answers():
+    """tiny-cuda-nn grid_index(): `uint32_t stride = 1; for (dim < N_DIMS && stride <= hashmap_size)
+    { index += pos[dim] * stride; stride *= resolution; } if (hashmap_size < stride) index = hash(pos);`
+    With res = 2^16 .. 2^19 (levels 12-15 of base 16 / scale 2) the second multiplication wraps to exactly 0:
+    no hash, index = (c0 + c1 * res) mod 2^32 mod 2^19, and a third dimension is multiplied by stride 0."""
+    T = 1 << 19
+    for dims in (2, 3):
+        geo = orc.geometry_from_config(dims, orc.encoding_config)
+        for lvl in (12, 13, 14, 15):
+            res = geo.resolutions[lvl]
+            assert res == 1 << (4 + lvl) and geo.sizes[lvl] == T and not geo.hashed[lvl]
+            # the same walk in plain Python integers
+            stride, walked = 1, []
+            for d in range(dims):
+                if stride > T:
+                    break
+                walked.append(stride)
+                stride = (stride * res) & 0xFFFFFFFF
+            assert stride == 0 and walked == [1, res] + [0] * (dims - 2)
+            cells = np.array([[1, 2, 3], [0xFFFFFFF1, 7, 99], [65535, 0xFFFFFFFF, 5], [2, 9, 0]], dtype=np.uint64)[:, :dims]
+            got = orc.grid_index(cells, geo, lvl).tolist()
+            exp = [int((int(c[0]) + int(c[1]) * res) & 0xFFFFFFFF) % T for c in cells]
+            assert got == exp
+        # level 15 (res = 2^19): c1 * 2^19 vanishes mod 2^19 -> the index is c0 alone
+        c = np.array([[5, 123456, 77][:dims], [5, 1, 2][:dims]], dtype=np.uint64)
+        assert orc.grid_index(c, geo, 15).tolist() == [5, 5]
+        # level 12 (res = 2^16): only the low 3 bits of c1 survive
+        c = np.array([[5, 8 + 3, 1][:dims], [5, 3, 2][:dims]], dtype=np.uint64)
+        assert orc.grid_index(c, geo, 12).tolist() == [5 + 3 * 65536] * 2
+        # level 11 (res = 2^15): res^2 = 2^30 > 2^19, no wrap -> still hashed
+        assert geo.hashed[11]
+    # a non-power-of-two scale does not wrap to 0: hashing stays on the fine levels
+    geo = orc.geometry_from_config(2, dict(orc.encoding_config, per_level_scale=1.9))
+    assert all(geo.hashed[l] for l in range(8, 16))
 
 
 def test_dense_index_negative_wrap():
@@ -109,3 +147,36 @@ def test_init_distribution():
     # different seeds / streams decorrelate
     q = orc.init_inr_params(g2, m, 1338)
     assert abs(np.corrcoef(p[:8192], q[:8192])[0, 1]) < 0.05
+
+
+def test_c_encode_matches_torch_expression():
+    """oracle/hashgrid_oracle.c (the C evaluation of the interpolation) vs the torch expression it restates:
+    forward bit-exact, backward to fp32 rounding, every summation order."""
+    g = torch.Generator().manual_seed(3)
+    for dims, n in ((2, 9001), (3, 5003)):
+        geo = orc.geometry_from_config(dims, orc.encoding_config)
+        coords = torch.rand(n, dims, generator=g) * 2 - 1
+        table = torch.rand(geo.n_entries, 2, generator=g) - 0.5
+        denc = torch.randn(n, 32, generator=g)
+        plan = orc.HashGridPlan(coords, geo)
+        t0 = table.clone().requires_grad_(True)
+        e0 = plan.encode_torch(t0)
+        (e0 * denc).sum().backward()
+        for order in (0, 1, 2, 7):
+            plan.bwd_order = order
+            t1 = table.clone().requires_grad_(True)
+            e1 = plan.encode_c(t1)
+            assert torch.equal(e1, e0)
+            (e1 * denc).sum().backward()
+            assert (t1.grad - t0.grad).abs().max() <= 1e-5 * t0.grad.abs().max()
+            assert torch.equal(t1.grad == 0, t0.grad == 0)      # the same entries are touched
+    # lattice with many points per entry (the wrapped-stride levels): large sums stay within rounding
+    geo = orc.geometry_from_config(3, orc.encoding_config)
+    x = orc.make_grids((2, 40, 40))
+    plan = orc.HashGridPlan(x, geo)
+    denc = torch.randn(x.shape[0], 32, generator=g)
+    t0 = torch.zeros(geo.n_entries, 2, requires_grad=True)
+    (plan.encode_torch(t0) * denc).sum().backward()
+    t1 = torch.zeros(geo.n_entries, 2, requires_grad=True)
+    (plan.encode_c(t1) * denc).sum().backward()
+    assert (t1.grad - t0.grad).abs().max() <= 2e-5 * t0.grad.abs().max()

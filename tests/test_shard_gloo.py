@@ -30,6 +30,14 @@ def _worker(rank, world, port, n_slices, dst, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if n_slices < world:
+            # fewer slices than ranks: EVERY rank refuses up front (nobody is left waiting in the collective)
+            try:
+                solve_sharded(n_slices, _fake_solve, dst=dst)
+                q.put((rank, False))
+            except ValueError:
+                q.put((rank, True))
+            return
         out = solve_sharded(n_slices, _fake_solve, dst=dst)
         ok = True
         if dst is None or rank == dst:
@@ -42,7 +50,7 @@ def _worker(rank, world, port, n_slices, dst, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_slices,dst", [(4, None), (5, None), (5, 0)])
+@pytest.mark.parametrize("n_slices,dst", [(4, None), (5, None), (5, 0), (1, None)])
 def test_sharded_solve_and_gather_world2(n_slices, dst):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import miccai24_immoco_amd as pkg
-from miccai24_immoco_amd import synth
+from oracle import synth_cpu as synth
 from miccai24_immoco_amd.utils.evaluate import crop_psnr
 g = np.load(os.path.join(ROOT, "tests/golden/c2_oracle_slice1_300it.npz"))
 ol = g["loss"].astype(np.float64)

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import miccai24_immoco_amd as pkg
-from miccai24_immoco_amd import synth
+from oracle import synth_cpu as synth
 from miccai24_immoco_amd.models.immoco import get_solver, lambda_schedule
 from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
 from miccai24_immoco_amd.utils.evaluate import crop_psnr

@@ -103,6 +103,17 @@ def main():
     ops["normalize_a"] = ref_ev.normalize(a).numpy()
     ops["psnr_ab"] = np.float32(ref_ev.my_psnr(ref_ev.normalize(a), ref_ev.normalize(b), data_range=1.0))
     ops["rmse_ab"] = np.float32(ref_ev.rmse(ref_ev.normalize(a), ref_ev.normalize(b)))
+    # gradients THROUGH the reference's FFT / IFFT (torch autograd) for odd and even sizes: pins the adjoints
+    # of the package's centred transforms (odd sizes: fftshift and ifftshift are different rolls)
+    g2 = torch.Generator().manual_seed(23)
+    for tag, shape in (("odd", (2, 5, 7)), ("even", (2, 6, 8))):
+        x = torch.complex(torch.randn(shape, generator=g2), torch.randn(shape, generator=g2)).requires_grad_(True)
+        y = torch.complex(torch.randn(shape, generator=g2), torch.randn(shape, generator=g2))
+        ops[f"adj_{tag}_x"], ops[f"adj_{tag}_y"] = x.detach().numpy(), y.numpy()
+        for name, fn in (("fft", ref_du.FFT), ("ifft", ref_du.IFFT)):
+            x.grad = None
+            (torch.view_as_real(fn(x)) * torch.view_as_real(y)).sum().backward()
+            ops[f"adj_{tag}_{name}_grad"] = x.grad.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **ops)
 
     # ---------------- B. line-select masks (bit-exact integer path) ----------------
