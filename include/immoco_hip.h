@@ -83,6 +83,14 @@ int immoco_hashgrid_fwd(const immoco_grid_cfg* cfg, const float* coords /*[n,dim
 int immoco_hashgrid_fwd_f16(const immoco_grid_cfg* cfg, const float* coords /*[n,dims]*/, int64_t n,
                             const void* table_f16, float* enc, int64_t enc_point_stride,
                             int64_t enc_level_stride, void* stream);
+/* The same encoding for the LATTICE the reference always queries (immoco.py:48-53,72-80) given by its axes
+ * instead of n coordinate rows: dims = 3: point (m, row, col) = (ax0[m], ax1[row], ax2[col]), n = nM*H*W
+ * points in (m, row, col) order; dims = 2: point (row, col) = (x = ax0[col], y = ax1[row]), nM = 1, ax2 unused
+ * (the conventions of immoco_grid_plan_create).  Bit-identical to immoco_hashgrid_fwd on the expanded
+ * coordinates; the solver's path (wave-uniform motion group: merged / lane-paired dim-0 corner loads). */
+int immoco_hashgrid_fwd_lattice(const immoco_grid_cfg* cfg, int32_t nM, int32_t H, int32_t W, const float* ax0,
+                                const float* ax1, const float* ax2, const float* table, float* enc,
+                                int64_t enc_point_stride, int64_t enc_level_stride, void* stream);
 /* Accumulates dtable[n_entries][2] += scatter(denc) (same strides as fwd). */
 int immoco_hashgrid_bwd(const immoco_grid_cfg* cfg, const float* coords, int64_t n,
                         const float* denc, int64_t enc_point_stride, int64_t enc_level_stride,
@@ -212,7 +220,13 @@ typedef struct immoco_solver_cfg {
   int32_t table_fp16;     /* 1: gather the hash-grid features from fp16 shadows of the tables (what
                              tiny-cuda-nn does; BASELINE config 5), fp32 master tables + fp32 Adam;
                              default 0: everything fp32 */
-  int32_t reserved[3];
+  int32_t batch_lanes;    /* immoco_solver_solve_batch keeps this many slices IN FLIGHT side by side (each on its
+                             own workspace, streams and captured graph; the transposed indices are shared):
+                             while one slice sits in an L2-bandwidth-bound hash-grid gather another one runs its
+                             MFMA-/HBM-bound kernels.  0 or 1: slice after slice */
+  int32_t gather_waves;   /* occupancy cap (waves per SIMD, 1..8; 0 = no cap) of the hash-grid gather kernels, so
+                             that kernels of another slice in flight find room on the CUs beside them */
+  int32_t reserved[1];
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;
@@ -248,7 +262,8 @@ int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t
 /* The same for a batch of B slices of the solver's shape (BASELINE config 3; SURVEY §8b "over a batch
  * dimension B of slices"): every buffer gains a leading dimension B - kspace_in [B,H,W] c64, col_group
  * [B,W], params_* [B,n_params], adam_* [B,2*n_params], out_* [B,H,W] c64, loss_hist [B,iters] or NULL;
- * lambda_sched / lr / step0 are shared.  Slices are solved one after the other on the solver's streams. */
+ * lambda_sched / lr / step0 are shared.  cfg.batch_lanes slices are in flight at a time (slice i runs on lane
+ * i % lanes); the call returns when everything is queued, outputs are ordered on `stream`. */
 int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const float* kspace_in, const int32_t* col_group,
                               float* params_image, float* params_motion, float* adam_image, float* adam_motion,
                               int32_t iters, float lr, const float* lambda_sched, int32_t step0,

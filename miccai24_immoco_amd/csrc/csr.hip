@@ -10,7 +10,9 @@
 // contributions, slot-sorted, built on the GPU (count -> hipCUB exclusive scan -> fill), plus a
 // host-built list of work items.  An entry is 8 bytes: {point (relative to its part) << 11 | slot
 // (relative to its 2048-slot block), interpolation weight fp32}; a "twin" entry (sign bit of the weight
-// set) stands for both dim-0 corners of its point: even slot | swap bit, weight of the other dimensions.  Earlier versions stored 4 bytes
+// set) stands for BOTH dim-0 corners of its point whenever they fall into one slot block: it is filed under the
+// low corner's slot and carries the weight of the other dimensions; the dim-0 fraction and the partner slot
+// (slot + 1 on dense levels, slot ^ (c0 ^ (c0+1)) on hashed ones) come from per-level tables.  Earlier versions stored 4 bytes
 // (corner | col | row | m) and recomputed slot and weight per entry from LDS axis tables: an
 // ablation on MI355X showed that this decode/hash/weight ALU work was 70 % of the kernel
 // (0.63 ms with, 0.45 ms without the gathers), so the plan now pays 4 more bytes of (otherwise
@@ -137,6 +139,10 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
       // Stored once at the even slot: slot LSB = 1 when the even slot belongs to the HIGH dim-0 corner,
       // weight = -(product of the other dimensions' factors); the dim-0 fraction comes from a per-level
       // table at run time.  One dL/denc gather then serves two slots.
+      // (Round 2 tried the general rule - any dim-0 pair inside one slot block, partner at slot ^ (c0 ^ (c0+1))
+      // on hashed levels: 35 % fewer entries and gathers, 59 M instead of 90 M, but the partner sums need
+      // scattered LDS float atomics, which cost 3 clocks PER LANE on this chip (tools/bench_lds_atomic.hip):
+      // 0.58 / 0.48 ms instead of 0.43.)
       const uint32_t even = idx[pair][0] & ~1u, swap = idx[pair][0] & 1u;
       const uint32_t key = kbase + even;
       const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);
@@ -179,7 +185,7 @@ struct BwdItem {
 // are each 1 KiB contiguous (coalesced) while lane `lane` still receives the 16 CONSECUTIVE sorted
 // entries 16*lane .. 16*lane+15 of the chunk.  (Thread-contiguous 128-byte reads were measured
 // 25 % slower: each of the 8 loads touches 64 different lines.)  Chunks are padded with entries
-// {point 0, slot 0, weight 0}, which add 0 and need no masking.
+// {point 0, slot of the last entry, weight 0}, which add 0 to the last run and need no masking.
 constexpr int WAVE_CHUNK = 1024;
 
 __global__ __launch_bounds__(256) void csr_permute_kernel(const BwdItem* __restrict__ items,
@@ -187,7 +193,9 @@ __global__ __launch_bounds__(256) void csr_permute_kernel(const BwdItem* __restr
   const BwdItem it = items[blockIdx.x];
   const uint32_t n_e = it.e1 - it.e0, n_pad = it.n_wc * WAVE_CHUNK;
   for (uint32_t s = threadIdx.x; s < n_pad; s += 256) {
-    const uint2 v = s < n_e ? sorted[it.e0 + s] : make_uint2(0u, 0u);
+    // padding: point 0, weight 0, the slot of the last real entry - it EXTENDS the last run (the backward
+    // stores run sums with plain LDS stores, so a stray run on another slot would overwrite that slot's sum)
+    const uint2 v = s < n_e ? sorted[it.e0 + s] : make_uint2(sorted[it.e1 - 1].x & (SLOTS_PER_ITEM - 1), 0u);
     const uint32_t wc = s / WAVE_CHUNK, lane = (s % WAVE_CHUNK) / 16, k = s % 16;
     out[(size_t)it.pe0 + (size_t)wc * WAVE_CHUNK + ((k >> 1) * 64 + lane) * 2 + (k & 1)] = v;
   }
@@ -205,7 +213,18 @@ __global__ __launch_bounds__(256) void csr_permute_kernel(const BwdItem* __restr
 // -> both gather kernels sit at the L1 miss-concurrency limit (~175 G L2 requests/s chip-wide).
 constexpr int EPT = 16;                  // entries per thread per chunk
 
-// PAIR: the plan holds twin entries (motion grid): a run is a slot PAIR and carries four sums.
+// v7 (round 2): NO scattered LDS float atomics.  tools/bench_lds_atomic.hip: ds_add_f32 costs ~3 clocks per
+// ACTIVE LANE per CU (193 clocks for a full wave instruction, whatever the addresses; ds_add_u32: 8), so the
+// "one LDS atomic per run" of v3-v6 - about 0.75 lane-atomics per entry - was 2.2 of the kernel's 2.9 clocks
+// per entry, not the gathers.  Entries are slot-sorted and a lane owns 16 CONSECUTIVE ones, so a run (all
+// entries of one slot, or of one slot pair with twin entries) is a contiguous range of the chunk:
+//   * a run that lies inside one lane is written with a plain LDS store;
+//   * a run that spans two lanes: the right lane hands its head partial sum to the left lane through a
+//     DPP/permute shift, the left lane (which holds the run's first entry) adds it and stores;
+//   * only what is left - lanes that lie wholly inside a longer run, and lane 0 of a chunk (its left
+//     neighbour is another wave) - uses float atomics, into a SECOND tile, so that they never race with
+//     the plain stores; the result is the sum of the two tiles.
+// Exactly one lane holds a run's first entry, so every slot gets at most one plain store.
 template <int DIMS, bool PAIR>  // DIMS names the instantiation (2: image grid, 3: motion grid) in profiles
 __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
@@ -214,12 +233,17 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
                                                       float* __restrict__ dtable, int64_t part_stride,
                                                       int zeroed, const float* __restrict__ f0tab, int n0,
                                                       uint32_t hw, float inv_hw) {
-  __shared__ float acc[2 * SLOTS_PER_ITEM];
+  constexpr int NS = PAIR ? 4 : 2;                     // sums per run: (even.x, even.y, odd.x, odd.y) or (x, y)
+  __shared__ __attribute__((aligned(16))) float accA[2 * SLOTS_PER_ITEM];  // plain stores: one per run
+  __shared__ __attribute__((aligned(16))) float accB[2 * SLOTS_PER_ITEM];  // float atomics: the leftovers
   __shared__ float f0s[PAIR ? 256 : 1];
   const BwdItem it = items[blockIdx.x];
   if (it.n_wc == 0) return;  // padding item of the XCD interleave
   const int tid = threadIdx.x;
-  for (int i = tid; i < 2 * (int)it.ns; i += 256) acc[i] = 0.f;
+  for (int i = tid; i < 2 * (int)it.ns; i += 256) {
+    accA[i] = 0.f;
+    accB[i] = 0.f;
+  }
   if (PAIR && tid < n0) f0s[tid] = f0tab[it.level * n0 + tid];
   __syncthreads();
   const uint32_t part = it.part_shared & 0xFFFFu;
@@ -232,6 +256,14 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
 #pragma unroll
     for (int j = 0; j < EPT / 2; ++j) q[j] = e4[(size_t)wave * (WAVE_CHUNK / 2) + j * 64 + lane];
   }
+  auto store_run = [&](uint32_t unit, const float (&v)[NS]) {   // unit: slot (NS = 2) or slot pair (NS = 4)
+    if (PAIR) *reinterpret_cast<float4*>(&accA[4 * unit]) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<float2*>(&accA[2 * unit]) = make_float2(v[0], v[1]);
+  };
+  auto atomic_run = [&](uint32_t unit, const float (&v)[NS]) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) atomicAdd(&accB[NS * unit + j], v[j]);
+  };
   for (uint32_t wc = wave; wc < it.n_wc; wc += 4) {
     uint32_t key[EPT];
     float wt[EPT];
@@ -249,13 +281,20 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
     float2 g[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) g[k] = dl[key[k] >> SLOT_BITS];
-    if (PAIR) {
-      // run-length accumulate over slot pairs: (even.x, even.y, odd.x, odd.y) = acc[4*pair .. 4*pair+3]
-      uint32_t cur = (key[0] & (SLOTS_PER_ITEM - 1)) >> 1;
-      float e0 = 0.f, e1 = 0.f, o0 = 0.f, o1 = 0.f;
+    // run-length accumulate; the head run (the one that contains entry 0) is kept aside, runs in the
+    // middle of the lane are stored at once, the tail run stays in s[]
+    const uint32_t first = (key[0] & (SLOTS_PER_ITEM - 1)) >> (PAIR ? 1 : 0);
+    uint32_t cur = first;
+    float s[NS], hs[NS];
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1), pr = loc >> 1;
+    for (int j = 0; j < NS; ++j) s[j] = hs[j] = 0.f;
+    bool single = true;  // the lane has seen one run only so far
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1);
+      const uint32_t unit = PAIR ? loc >> 1 : loc;
+      float c[NS];
+      if (PAIR) {
         const bool twin = __float_as_uint(wt[k]) >> 31, odd = loc & 1u;
         const float w = fabsf(wt[k]);
         // dim-0 lattice index of the point (exact: p < 2^24, one correction step each way)
@@ -268,58 +307,64 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
         const float fe = odd ? f : 1.f - f;
         const float we = twin ? w * fe : (odd ? 0.f : w);
         const float wo = twin ? w * (1.f - fe) : (odd ? w : 0.f);
-        if (pr != cur) {
-          atomicAdd(&acc[4 * cur], e0);
-          atomicAdd(&acc[4 * cur + 1], e1);
-          atomicAdd(&acc[4 * cur + 2], o0);
-          atomicAdd(&acc[4 * cur + 3], o1);
-          cur = pr;
-          e0 = e1 = o0 = o1 = 0.f;
-        }
-        e0 = fmaf(we, g[k].x, e0);
-        e1 = fmaf(we, g[k].y, e1);
-        o0 = fmaf(wo, g[k].x, o0);
-        o1 = fmaf(wo, g[k].y, o1);
+        c[0] = we * g[k].x;
+        c[1] = we * g[k].y;
+        c[2] = wo * g[k].x;
+        c[3] = wo * g[k].y;
+      } else {
+        c[0] = wt[k] * g[k].x;
+        c[1] = wt[k] * g[k].y;
       }
-      atomicAdd(&acc[4 * cur], e0);
-      atomicAdd(&acc[4 * cur + 1], e1);
-      atomicAdd(&acc[4 * cur + 2], o0);
-      atomicAdd(&acc[4 * cur + 3], o1);
-    } else {
-      // run-length accumulate
-      uint32_t cur = key[0] & (SLOTS_PER_ITEM - 1);
-      float s0 = 0.f, s1 = 0.f;
+      if (unit != cur) {
+        if (single) {
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const uint32_t loc = key[k] & (SLOTS_PER_ITEM - 1);
-        if (loc != cur) {
-          atomicAdd(&acc[2 * cur], s0);
-          atomicAdd(&acc[2 * cur + 1], s1);
-          cur = loc;
-          s0 = s1 = 0.f;
+          for (int j = 0; j < NS; ++j) hs[j] = s[j];
+          single = false;
+        } else {
+          store_run(cur, s);
         }
-        s0 = fmaf(wt[k], g[k].x, s0);
-        s1 = fmaf(wt[k], g[k].y, s1);
+        cur = unit;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) s[j] = 0.f;
       }
-      atomicAdd(&acc[2 * cur], s0);
-      atomicAdd(&acc[2 * cur + 1], s1);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] += c[j];
+    }
+    // does the lane's first run continue the previous lane's last one?  (lane 0: unknown -> treated as open)
+    const uint32_t prev_cur = __shfl_up(cur, 1, 64);
+    const bool open_left = lane == 0 || prev_cur == first;
+    // a lane with >= 2 runs hands an open head to its left neighbour, which holds that run's first entry
+    // or is itself wholly inside it (then it goes on to the atomics below)
+    const bool send = open_left && !single && lane != 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const float r = __shfl_down(send ? hs[j] : 0.f, 1, 64);
+      s[j] += lane == 63 ? 0.f : r;
+    }
+    if (single) {
+      if (open_left) atomic_run(cur, s);
+      else store_run(cur, s);
+    } else {
+      store_run(cur, s);            // the tail run began in this lane
+      if (!open_left) store_run(first, hs);
+      else if (lane == 0) atomic_run(first, hs);
     }
   }
   __syncthreads();
   float* __restrict__ out = dtable + (size_t)part * part_stride + (size_t)it.s0 * 2;
   if (it.part_shared >> 16) {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
-      const float v = acc[i];
+      const float v = accA[i] + accB[i];
       if (v != 0.f) unsafeAtomicAdd(out + i, v);
     }
   } else if (zeroed) {
     // exclusive owner of these (part, slot) pairs: no atomics.  Solver mode (`zeroed`): the tile is
     // OVERWRITTEN every iteration (zeros included), so nobody has to clear it (Adam's fused
     // zero_grad skips these ranges: 16 B/param less HBM traffic); op-level mode accumulates.
-    for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = acc[i];
+    for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = accA[i] + accB[i];
   } else {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
-      const float v = acc[i];
+      const float v = accA[i] + accB[i];
       if (v != 0.f) out[i] += v;
     }
   }
@@ -526,12 +571,13 @@ const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n) {
 // that the buffers hold zeros or stale values of the same plan (plain stores); otherwise the
 // results are accumulated.
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride, int zeroed,
-                   hipStream_t st) {
+                   hipStream_t st, int occ_waves) {
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
   const uint32_t hw = (uint32_t)pl->H * (uint32_t)pl->W;
 #define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
-  csr_bwd_kernel<D, PAIR><<<pl->n_items, 256, 0, st>>>(n, pl->part_size, pl->items, pl->entries,                 \
+  csr_bwd_kernel<D, PAIR><<<pl->n_items, 256, occupancy_cap_lds(occ_waves, 34 * 1024), st>>>(                    \
+                                                       n, pl->part_size, pl->items, pl->entries,                 \
                                                        (const float2*)denc_level_major, dtable, part_stride,     \
                                                        zeroed, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw)
   if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);

@@ -139,6 +139,12 @@ __device__ __forceinline__ float2 encode_point_level(const Levels& lv, int l, co
   return make_float2(a0, a1);
 }
 
+// Measured dead end (round 2): for an ODD wave-uniform dim-0 cell the two dim-0 corners are not an aligned
+// pair, but they share a 128-byte line; putting them into adjacent lanes of ONE load (lane 2i low, 2i+1 high
+// corner, two rounds of 32 points, products exchanged by DPP, bit-identical) halves the distinct lines per
+// instruction - and changed nothing (0.278 -> 0.291 ms): the second corner's load already merges into the
+// first one's outstanding L1 miss, so a pair costs one L2->L1 fill either way.  The forward is bound by 4 line
+// fills per (point, hashed level).
 template <int D, bool LAT, typename TAB = float2>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const float* __restrict__ coords,
                                                            Lattice lat, int64_t n,
@@ -196,19 +202,20 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(Levels lv, con
 }
 
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
-                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st) {
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st, int occ_waves) {
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "encoding strides must be even (float2 stores)");
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   Lattice L{};
   if (lat) L = *lat;
   const float2* t = reinterpret_cast<const float2*>(table);
+  const unsigned lds = occupancy_cap_lds(occ_waves, 0);
   if (lv.dims == 2) {
-    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
-    else hashgrid_fwd_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    else hashgrid_fwd_kernel<2, false><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
   } else {
-    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
-    else hashgrid_fwd_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    else hashgrid_fwd_kernel<3, false><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
   }
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
@@ -216,12 +223,13 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
 
 // forward from the fp16 shadow table (lattice mode only: the solver's path)
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
-                             int64_t ps, int64_t ls, hipStream_t st) {
+                             int64_t ps, int64_t ls, hipStream_t st, int occ_waves) {
   if (n == 0) return IMMOCO_OK;
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   const __half2* t = reinterpret_cast<const __half2*>(table_half2);
-  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
-  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
+  const unsigned lds = occupancy_cap_lds(occ_waves, 0);
+  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, lds, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
+  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, lds, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
@@ -307,6 +315,30 @@ extern "C" int immoco_hashgrid_fwd(const immoco_grid_cfg* cfg, const float* coor
   IMMOCO_REQUIRE(n >= 0 && (n == 0 || (coords && table && enc)), "hashgrid_fwd: NULL buffer");
   return launch_hashgrid_fwd(lv, coords, nullptr, n, table, enc, enc_point_stride, enc_level_stride,
                              as_stream(stream));
+}
+
+extern "C" int immoco_hashgrid_fwd_lattice(const immoco_grid_cfg* cfg, int32_t nM, int32_t H, int32_t W,
+                                           const float* ax0, const float* ax1, const float* ax2, const float* table,
+                                           float* enc, int64_t enc_point_stride, int64_t enc_level_stride,
+                                           void* stream) {
+  Levels lv;
+  int rc = build_levels(cfg, &lv);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(nM >= 1 && H >= 1 && W >= 1, "hashgrid_fwd_lattice: bad lattice %dx%dx%d", nM, H, W);
+  IMMOCO_REQUIRE(ax0 && ax1 && (lv.dims == 2 || ax2) && table && enc, "hashgrid_fwd_lattice: NULL buffer");
+  IMMOCO_REQUIRE(lv.dims == 3 || nM == 1, "hashgrid_fwd_lattice: a 2-D grid takes nM = 1");
+  Lattice lat{};
+  if (lv.dims == 3) {  // (m, row, col)
+    lat.axis[0] = ax0; lat.n[0] = nM; lat.stride[0] = H * W;
+    lat.axis[1] = ax1; lat.n[1] = H;  lat.stride[1] = W;
+    lat.axis[2] = ax2; lat.n[2] = W;  lat.stride[2] = 1;
+  } else {             // (x = col, y = row)
+    lat.axis[0] = ax0; lat.n[0] = W; lat.stride[0] = 1;
+    lat.axis[1] = ax1; lat.n[1] = H; lat.stride[1] = W;
+    lat.axis[2] = ax0; lat.n[2] = 1; lat.stride[2] = 1;
+  }
+  return launch_hashgrid_fwd(lv, nullptr, &lat, (int64_t)nM * H * W, table, enc, enc_point_stride,
+                             enc_level_stride, as_stream(stream));
 }
 
 extern "C" int immoco_hashgrid_fwd_f16(const immoco_grid_cfg* cfg, const float* coords, int64_t n,

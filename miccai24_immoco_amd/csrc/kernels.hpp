@@ -12,10 +12,17 @@ struct Lattice {
 };
 
 // hashgrid.hip
+// occ_waves: occupancy cap in waves per SIMD (3..8; 0 = none), realised with unused dynamic LDS, so that
+// kernels of another slice in flight find free wave slots / registers beside this gather
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
-                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st);
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st, int occ_waves = 0);
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
-                             int64_t ps, int64_t ls, hipStream_t st);
+                             int64_t ps, int64_t ls, hipStream_t st, int occ_waves = 0);
+static inline unsigned occupancy_cap_lds(int occ_waves, unsigned static_lds) {
+  if (occ_waves < 3 || occ_waves > 8) return 0u;   // (2 would need > 64 KB of LDS per workgroup)
+  const unsigned per_wg = 160u * 1024u / (unsigned)occ_waves;  // a 256-thread workgroup = one wave per SIMD
+  return per_wg > static_lds + 512u ? per_wg - static_lds - 512u : 0u;
+}
 int launch_f32_to_half(const float* in, void* out_half, int64_t n, hipStream_t st);
 int launch_hashgrid_bwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
                         const float* denc, int64_t ps, int64_t ls, float* dtable, hipStream_t st);
@@ -104,7 +111,7 @@ int csr_plan_parts(const CsrPlan* p);
 // flushed with atomics and have to be cleared by the consumer, unlisted blocks never get a gradient
 const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n);
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,
-                   int zeroed, hipStream_t st);
+                   int zeroed, hipStream_t st, int occ_waves = 0);
 
 // masks.hip
 int launch_extract_groups(const uint8_t* lines, int n, int32_t* col_group, int32_t* n_groups, hipStream_t st);

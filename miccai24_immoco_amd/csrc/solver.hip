@@ -66,6 +66,13 @@ struct immoco_solver {
   // phase timing of the last profile call
   std::vector<std::string> phase_names;
   std::vector<float> phase_ms;
+  // batch lanes (immoco_solver_solve_batch): further workspaces that share this solver's lattices and plans
+  immoco_solver* parent = nullptr;
+  std::vector<immoco_solver*> lanes;
+  // schedule arrays currently on the device (re-uploading them needs a host sync of the lane's stream)
+  std::vector<float> sched_host;
+  // graph executables replaced while their launches may still be queued: destroyed once the event is done
+  std::vector<std::pair<hipGraphExec_t, hipEvent_t>> retired;
 };
 
 namespace {
@@ -124,8 +131,10 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   if (nM > 0) {
     st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
                     if (s->cfg.table_fp16)
-                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, 2, 2 * NP, q);
-                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
+                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, 2, 2 * NP, q,
+                                                      s->cfg.gather_waves);
+                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q,
+                                               s->cfg.gather_waves);
                   }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
@@ -158,7 +167,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   }});  // before the fork: the image chain's MFMA-bound MLP backward then runs beside the
                         // gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
-                    if (s->plan_mot) return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q);
+                    if (s->plan_mot)
+                      return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q, s->cfg.gather_waves);
                     return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
                   }, 1});
   }
@@ -209,6 +219,34 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   return st;
 }
 
+// A graph executable must outlive its queued launches: a solve that needs a new capture (other slice, other
+// buffers) parks the old one behind an event on the stream instead of destroying it under the GPU's feet.
+void retire_graph(immoco_solver* s) {
+  if (!s->gexec) return;
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, s->stream) == hipSuccess) {
+    s->retired.emplace_back(s->gexec, ev);
+  } else {  // fall back to draining the stream
+    (void)hipStreamSynchronize(s->stream);
+    hipGraphExecDestroy(s->gexec);
+    if (ev) hipEventDestroy(ev);
+  }
+  s->gexec = nullptr;
+}
+void sweep_retired(immoco_solver* s, bool wait) {
+  for (size_t i = 0; i < s->retired.size();) {
+    if (wait) (void)hipEventSynchronize(s->retired[i].second);
+    if (hipEventQuery(s->retired[i].second) == hipSuccess) {
+      hipGraphExecDestroy(s->retired[i].first);
+      hipEventDestroy(s->retired[i].second);
+      s->retired.erase(s->retired.begin() + i);
+    } else {
+      ++i;
+    }
+  }
+  (void)hipGetLastError();  // hipErrorNotReady of the query is not an error
+}
+
 int run_steps(const std::vector<Step>& steps, hipStream_t q) {
   for (const Step& st : steps) {
     int rc = st.run(q);
@@ -228,11 +266,10 @@ int ensure_sched(immoco_solver* s, int32_t iters) {
   IMMOCO_CHECK_HIP(hipMalloc((void**)&s->sched, (size_t)iters * 2 * sizeof(float)));
   IMMOCO_CHECK_HIP(hipMalloc((void**)&s->lambda_dev, (size_t)iters * sizeof(float)));
   s->sched_cap = iters;
-  // the schedule pointers are baked into a captured graph
-  if (s->gexec) {
-    hipGraphExecDestroy(s->gexec);
-    s->gexec = nullptr;
-  }
+  s->sched_host.clear();
+  // the schedule pointers are baked into a captured graph (the old arrays were freed above: drain first)
+  retire_graph(s);
+  sweep_retired(s, true);
   return IMMOCO_OK;
 }
 
@@ -377,7 +414,16 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
 
 extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   if (!s) return IMMOCO_OK;
+  for (immoco_solver* lane : s->lanes) immoco_solver_destroy(lane);
+  s->lanes.clear();
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->side) (void)hipStreamSynchronize(s->side);
   if (s->gexec) hipGraphExecDestroy(s->gexec);
+  sweep_retired(s, true);
+  if (s->parent) {  // a lane borrows lattices and plans from its parent
+    s->plan_img = s->plan_mot = nullptr;
+    s->xs = s->ys = s->ms = nullptr;
+  }
   csr_plan_free(s->plan_img);
   csr_plan_free(s->plan_mot);
   float* bufs[] = {s->xs, s->ys, s->ms, s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
@@ -400,7 +446,10 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
 }
 
 extern "C" int64_t immoco_solver_workspace_bytes(immoco_solver_t s) {
-  return s ? s->bytes + csr_plan_bytes(s->plan_img) + csr_plan_bytes(s->plan_mot) : 0;
+  if (!s) return 0;
+  int64_t b = s->bytes + csr_plan_bytes(s->plan_img) + csr_plan_bytes(s->plan_mot);
+  for (immoco_solver* lane : s->lanes) b += lane->bytes;
+  return b;
 }
 
 extern "C" int64_t immoco_solver_n_params(immoco_solver_t s, int32_t which) {
@@ -417,13 +466,13 @@ extern "C" int immoco_solver_set_lattice(immoco_solver_t s, const float* xs, con
   IMMOCO_CHECK_HIP(hipMemcpyAsync(s->ys, ys, (size_t)c.H * 4, hipMemcpyDeviceToDevice, caller));
   if (c.nM > 0) IMMOCO_CHECK_HIP(hipMemcpyAsync(s->ms, ms, (size_t)c.nM * 4, hipMemcpyDeviceToDevice, caller));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(caller));
+  for (immoco_solver* lane : s->lanes) immoco_solver_destroy(lane);  // they borrow the plans freed below
+  s->lanes.clear();
   csr_plan_free(s->plan_img);
   csr_plan_free(s->plan_mot);
   s->plan_img = s->plan_mot = nullptr;
-  if (s->gexec) {  // plans are baked into a captured graph
-    hipGraphExecDestroy(s->gexec);
-    s->gexec = nullptr;
-  }
+  retire_graph(s);  // plans are baked into a captured graph
+  sweep_retired(s, true);
   if (!c.atomic_scatter) {
     int rc;
     const float* ax2[3] = {s->xs, s->ys, nullptr};
@@ -439,11 +488,12 @@ extern "C" int immoco_solver_set_lattice(immoco_solver_t s, const float* xs, con
   return IMMOCO_OK;
 }
 
-extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
-                                   float* params_image,
-                                   float* params_motion, float* adam_image, float* adam_motion, int32_t iters,
-                                   float lr, const float* lambda_sched, int32_t step0, float* out_image,
-                                   float* out_kspace, float* loss_hist, void* stream) {
+namespace {
+// sync_in / sync_out: order the solve after / the caller's stream after it (a batch does this once per lane)
+int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_group, float* params_image,
+               float* params_motion, float* adam_image, float* adam_motion, int32_t iters, float lr,
+               const float* lambda_sched, int32_t step0, float* out_image, float* out_kspace, float* loss_hist,
+               void* stream, bool sync_in, bool sync_out) {
   IMMOCO_REQUIRE(s, "solver_solve: NULL solver");
   IMMOCO_REQUIRE(s->lattice_set, "solver_solve: call immoco_solver_set_lattice first");
   IMMOCO_REQUIRE(kspace_in && col_group && params_image && adam_image, "solver_solve: NULL buffer");
@@ -460,13 +510,21 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
     sched[2 * j + 1] = (float)sqrt(1.0 - pow(0.999, t));
     lam[j] = lambda_sched[j];
   }
-  if ((rc = enter(s, caller))) return rc;
+  if (sync_in && (rc = enter(s, caller))) return rc;
   hipStream_t q = s->stream;
-  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, q));
-  IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
+  // the schedules only change with (iters, lr, step0, lambda): a batch re-uses them slice after slice, and
+  // skipping the upload also skips the host sync it needs (the lane would drain before the next slice is queued)
+  std::vector<float> both(sched);
+  both.insert(both.end(), lam.begin(), lam.end());
+  if (both != s->sched_host) {
+    IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // nothing in flight may still read the old schedules
+    IMMOCO_CHECK_HIP(hipMemcpyAsync(s->sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, q));
+    IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
+    IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
+    s->sched_host.swap(both);
+  }
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   if (loss_hist) IMMOCO_CHECK_HIP(hipMemsetAsync(loss_hist, 0, (size_t)iters * 4, q));
-  IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
 
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
   if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
@@ -476,11 +534,9 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   if (s->cfg.use_graph) {
     std::vector<const void*> key = {kspace_in,  col_group,   params_image, params_motion,
                                     adam_image, adam_motion, loss_hist,    s->sched};
+    sweep_retired(s, false);
     if (!s->gexec || key != s->gkey) {
-      if (s->gexec) {
-        hipGraphExecDestroy(s->gexec);
-        s->gexec = nullptr;
-      }
+      retire_graph(s);
       hipGraph_t graph = nullptr;
       hipError_t e = hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
@@ -506,12 +562,47 @@ extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, co
   // tensors of the LAST forward pass (immoco.py:203-206)
   if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
   if (out_kspace && (rc = launch_transpose_c64(s->kout, out_kspace, s->cfg.W, s->cfg.H, q))) return rc;
-  return leave(s, caller);
+  return sync_out ? leave(s, caller) : IMMOCO_OK;
+}
+}  // namespace
+
+extern "C" int immoco_solver_solve(immoco_solver_t s, const float* kspace_in, const int32_t* col_group,
+                                   float* params_image,
+                                   float* params_motion, float* adam_image, float* adam_motion, int32_t iters,
+                                   float lr, const float* lambda_sched, int32_t step0, float* out_image,
+                                   float* out_kspace, float* loss_hist, void* stream) {
+  return solve_impl(s, kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, iters, lr,
+                    lambda_sched, step0, out_image, out_kspace, loss_hist, stream, true, true);
 }
 
-// Batch of B independent slices of one shape (BASELINE config 3): slice after slice on the solver's
-// stream - the gather kernels of one slice already fill the chip, so slices in flight
-// side by side bring no throughput.
+// Batch of B independent slices of one shape (BASELINE config 3).  cfg.batch_lanes slices are in flight side
+// by side: lane k is a full solver workspace (activations, gradient tables, streams, captured graph) that borrows
+// the parent's lattices and transposed indices; slice i is queued on lane i % lanes.  Nothing in a solve waits on
+// the host once the schedules are on the device, so the lanes' iteration graphs interleave on the GPU on their
+// own: while one slice sits in an L2-bandwidth-bound hash-grid gather, another runs its MFMA- and HBM-bound
+// kernels (MLPs, Adam, FFTs).
+namespace {
+int make_lane(immoco_solver* parent, immoco_solver** out) {
+  immoco_solver_cfg cfg = parent->cfg;
+  cfg.batch_lanes = 0;
+  immoco_solver* lane = nullptr;
+  int rc = immoco_solver_create(&cfg, &lane);
+  if (rc) return rc;
+  // borrow lattices and plans (freed by the parent only)
+  for (float* b : {lane->xs, lane->ys, lane->ms})
+    if (b) hipFree(b);
+  lane->xs = parent->xs;
+  lane->ys = parent->ys;
+  lane->ms = parent->ms;
+  lane->plan_img = parent->plan_img;
+  lane->plan_mot = parent->plan_mot;
+  lane->lattice_set = true;
+  lane->parent = parent;
+  *out = lane;
+  return IMMOCO_OK;
+}
+}  // namespace
+
 extern "C" int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const float* kspace_in,
                                          const int32_t* col_group, float* params_image, float* params_motion,
                                          float* adam_image, float* adam_motion, int32_t iters, float lr,
@@ -519,16 +610,31 @@ extern "C" int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const flo
                                          float* out_kspace, float* loss_hist, void* stream) {
   IMMOCO_REQUIRE(s, "solver_solve_batch: NULL solver");
   IMMOCO_REQUIRE(B >= 0, "solver_solve_batch: negative batch size %d", B);
+  IMMOCO_REQUIRE(B == 0 || s->lattice_set, "solver_solve_batch: call immoco_solver_set_lattice first");
   const int64_t P2 = 2 * s->P, W = s->cfg.W;
+  const int n_lanes = std::max(1, std::min<int>(s->cfg.batch_lanes, B));
+  while ((int)s->lanes.size() < n_lanes - 1) {  // lane 0 is the solver itself
+    immoco_solver* lane = nullptr;
+    int rc = make_lane(s, &lane);
+    if (rc) return rc;
+    s->lanes.push_back(lane);
+  }
+  // every lane starts after what the caller's stream holds now; the caller's stream waits for all lanes at the
+  // end (a wait per slice would serialise the lanes through the caller's stream)
   for (int32_t i = 0; i < B; ++i) {
-    int rc = immoco_solver_solve(
-        s, kspace_in ? kspace_in + i * P2 : nullptr, col_group ? col_group + i * W : nullptr,
+    immoco_solver* lane = (i % n_lanes) == 0 ? s : s->lanes[(i % n_lanes) - 1];
+    int rc = solve_impl(
+        lane, kspace_in ? kspace_in + i * P2 : nullptr, col_group ? col_group + i * W : nullptr,
         params_image ? params_image + i * s->n_params_img : nullptr,
         params_motion ? params_motion + i * s->n_params_mot : nullptr,
         adam_image ? adam_image + 2 * i * s->n_params_img : nullptr,
         adam_motion ? adam_motion + 2 * i * s->n_params_mot : nullptr, iters, lr, lambda_sched, step0,
         out_image ? out_image + i * P2 : nullptr, out_kspace ? out_kspace + i * P2 : nullptr,
-        loss_hist ? loss_hist + (int64_t)i * iters : nullptr, stream);
+        loss_hist ? loss_hist + (int64_t)i * iters : nullptr, stream, i < n_lanes, false);
+    if (rc) return rc;
+  }
+  for (int k = 0; k < n_lanes && k < B; ++k) {
+    int rc = leave(k == 0 ? s : s->lanes[k - 1], as_stream(stream));
     if (rc) return rc;
   }
   return IMMOCO_OK;
@@ -579,6 +685,7 @@ extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, 
   }
   if ((rc = enter(s, caller))) return rc;
   hipStream_t q = s->stream;
+  s->sched_host.clear();
   IMMOCO_CHECK_HIP(hipMemcpyAsync(s->sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, q));
   IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));

@@ -63,7 +63,8 @@ class _GridPlan:
 
     def __init__(self, grid_cfg, nM, H, W, axes):
         self.handle = C.c_void_p()
-        self.axes = axes  # keep the device arrays alive while the plan is built
+        self.nM, self.H, self.W = nM, H, W
+        self.axes = axes  # device arrays of the lattice axes (also read by the lattice forward kernel)
         L.check(L.lib().immoco_grid_plan_create(C.byref(grid_cfg), nM, H, W, L.ptr(axes[0]), L.ptr(axes[1]),
                                                 L.ptr(axes[2]), C.byref(self.handle), L.stream_ptr()),
                 "grid_plan_create")
@@ -92,12 +93,18 @@ class _INRFunction(torch.autograd.Function):
         enc = torch.empty((mod.grid_cfg.n_levels, n, 2), device=x.device, dtype=torch.float32)
         out = torch.empty((n, 2), device=x.device, dtype=torch.float32)
         lib, st = L.lib(), L.stream_ptr()
-        L.check(lib.immoco_hashgrid_fwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(tab), L.ptr(enc), 2, 2 * n, st),
-                "hashgrid_fwd")
+        plan = mod._plan_for(x, key)
+        if plan is not None:      # the reference's lattice: per-axis kernel (bit-identical, fewer cache lines)
+            L.check(lib.immoco_hashgrid_fwd_lattice(C.byref(mod.grid_cfg), plan.nM, plan.H, plan.W, L.ptr(plan.axes[0]),
+                                                    L.ptr(plan.axes[1]), L.ptr(plan.axes[2]), L.ptr(tab), L.ptr(enc),
+                                                    2, 2 * n, st), "hashgrid_fwd_lattice")
+        else:
+            L.check(lib.immoco_hashgrid_fwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(tab), L.ptr(enc), 2, 2 * n, st),
+                    "hashgrid_fwd")
         L.check(lib.immoco_mlp_fwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(out), st),
                 "mlp_fwd")
         ctx.mod = mod
-        ctx.plan = mod._plan_for(x, key)
+        ctx.plan = plan
         ctx.save_for_backward(x, params, enc)
         return out
 

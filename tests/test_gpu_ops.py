@@ -71,6 +71,39 @@ def test_hashgrid_fwd_bit_exact_and_bwd(env, dims):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("shape", [(2, (5, 16, 24)), (3, (7, 24, 40)), (3, (10, 9, 13)), (3, (1, 32, 32)), (2, (1, 30, 21))])
+def test_hashgrid_fwd_lattice_bit_exact(env, shape):
+    """The per-axis lattice kernel (solver path: dwordx4-merged even and lane-paired odd dim-0 cells, waves that
+    straddle two motion groups, ragged tails) == the oracle, bit for bit, fp32 and fp16 tables."""
+    pkg, L, orc = env
+    dims, sizes = shape
+    nM, H, W = sizes if dims == 3 else (1,) + sizes[1:]
+    g = torch.Generator().manual_seed(sum(sizes))
+    if dims == 3:
+        coords = orc.make_grids((nM, H, W))
+        axes = [torch.linspace(-1, 1, k) for k in (nM, H, W)]
+    else:
+        coords = orc.identity_grid(H, W).view(-1, 2)
+        axes = [torch.linspace(-1, 1, W), torch.linspace(-1, 1, H), torch.linspace(-1, 1, W)]
+    n = coords.shape[0]
+    geo = orc.geometry_from_config(dims, orc.encoding_config)
+    table = torch.rand(geo.n_entries, 2, generator=g) - 0.5
+    ref = orc.HashGridPlan(coords, geo).encode(table)
+    cfg = L.grid_cfg(dims, pkg.encoding_config)
+    ax = [a.cuda() for a in axes]
+    td = table.cuda()
+    enc = torch.full((16, n, 2), float("nan"), device="cuda")
+    L.check(L.lib().immoco_hashgrid_fwd_lattice(C.byref(cfg), nM, H, W, L.ptr(ax[0]), L.ptr(ax[1]), L.ptr(ax[2]),
+                                                L.ptr(td), L.ptr(enc), 2, 2 * n, L.stream_ptr()))
+    got = enc.cpu().permute(1, 0, 2).reshape(n, 32)
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max()}"
+    # and equal to the generic-coordinates kernel
+    enc2 = torch.empty((16, n, 2), device="cuda")
+    cd = coords.cuda().contiguous()
+    L.check(L.lib().immoco_hashgrid_fwd(C.byref(cfg), L.ptr(cd), n, L.ptr(td), L.ptr(enc2), 2, 2 * n, L.stream_ptr()))
+    assert torch.equal(enc2, enc)
+
+
 def test_grid_geometry_matches_oracle(env):
     pkg, L, orc = env
     for dims in (2, 3):

@@ -1,6 +1,9 @@
 """Run the CPU oracle on config C2 (320x320, 10 groups) for N iterations; log loss/PSNR; save npz.
 
-    python tools/oracle_c2.py <slice_idx> <iters> <out.npz> [order] [threads]
+    python tools/oracle_c2.py <slice_idx> <iters> <out.npz> [order] [threads] [sched_iters]
+
+`sched_iters` (default: iters) is the length of the solve whose lambda_GE schedule is used: `401 ... 3000` records
+the first 401 iterations of a 3000-iteration solve (a draw of the metric's trajectory), not a 401-iteration solve.
 
 `order` selects the fp32 summation order of the oracle's hash-grid backward (oracle/hashgrid_oracle.c:
 0 ascending, 1 descending, k >= 2 strided blocks) and `threads` torch's thread count (changes the blocking of
@@ -16,6 +19,7 @@ from oracle import immoco_oracle as orc, synth_cpu
 idx, iters, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 order = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 threads = int(sys.argv[5]) if len(sys.argv) > 5 else int(os.environ.get("ORACLE_THREADS", "4"))
+sched_iters = int(sys.argv[6]) if len(sys.argv) > 6 else iters
 torch.set_num_threads(threads)
 s = synth_cpu.make_slice(320, 320, 10, idx)
 masks = orc.extract_movement_groups(s["lines"], make_list=True)
@@ -26,7 +30,7 @@ model = orc.OracleIMMoCo(masks,
 k = s["kspace"]
 kin = k.div(k.abs().max()).mul(16000).clone()
 opt = torch.optim.Adam([{"params": model.motion_inr.parameters(), "lr": 1e-2}, {"params": model.image_inr.parameters(), "lr": 1e-2}])
-lam = orc.lambda_schedule(iters, 1e-2)
+lam = orc.lambda_schedule(sched_iters, 1e-2)
 hist, psnrs = [], {}
 t0 = time.time()
 for j in range(iters):
@@ -42,5 +46,5 @@ for j in range(iters):
     if j % 100 == 0 or j == iters - 1:
         np.savez_compressed(out, image=ip.detach().numpy(), kfm=kf.detach().numpy(), loss=np.array(hist, dtype=np.float64),
                             psnr_iters=np.array(list(psnrs.keys())), psnr=np.array(list(psnrs.values())), slice_idx=idx,
-                            iters=iters, iters_done=j + 1, order=order, threads=threads,
+                            iters=iters, sched_iters=sched_iters, iters_done=j + 1, order=order, threads=threads,
                             kspace=k.numpy(), lines=s["lines"].numpy(), n_groups=int(masks.shape[0]))
