@@ -212,21 +212,22 @@ typedef struct immoco_solver_cfg {
   int32_t use_graph;      /* 1: capture one iteration in a hipGraph and replay it */
   int32_t atomic_scatter; /* 1: hash-grid backward by global float atomics (slow reference path
                              kept for A/B measurements); 0: transposed-index gather (default) */
-  int32_t grad_parts;     /* point-range parts of the motion grid's transposed index (1, 2, 4 or 8;
+  int32_t grad_parts;     /* point-range parts of the motion grid's transposed index (a power of two <= 256;
                              0 = chosen from the lattice size so that one level slice of dL/denc per
-                             part is ~2 MB, the share of an XCD's L2: 4 at 320x320x10, 8 at 640x640x20) */
+                             part is ~2 MB, the share of an XCD's L2: 4 at 320x320x10, 32 at 640x640x20);
+                             up to 8 parts run in one launch, each into its own partial gradient table */
   int32_t serial_chains;  /* 1: run the image-INR and motion-INR kernel chains one after the other
                              (default 0: two concurrent branches of the graph) */
   int32_t table_fp16;     /* 1: gather the hash-grid features from fp16 shadows of the tables (what
                              tiny-cuda-nn does; BASELINE config 5), fp32 master tables + fp32 Adam;
                              default 0: everything fp32 */
   int32_t batch_lanes;    /* immoco_solver_solve_batch keeps this many slices IN FLIGHT side by side (each on its
-                             own workspace, streams and captured graph; the transposed indices are shared):
-                             while one slice sits in an L2-bandwidth-bound hash-grid gather another one runs its
-                             MFMA-/HBM-bound kernels.  0 or 1: slice after slice */
-  int32_t gather_waves;   /* occupancy cap (waves per SIMD, 1..8; 0 = no cap) of the hash-grid gather kernels, so
-                             that kernels of another slice in flight find room on the CUs beside them */
-  int32_t reserved[1];
+                             own workspace, streams and captured graph; the transposed indices are shared).
+                             0 or 1 (default, and the fastest on MI355X): slice after slice.  Measured at 320x320x10
+                             with the streams on separate hardware queues (GPU_MAX_HW_QUEUES=12): 2 lanes 1.55,
+                             3 lanes 1.65 ms per slice-iteration against 1.36 serial - two slices' hash-grid
+                             gathers evict each other's 4 MB level slices from the XCD L2s */
+  int32_t reserved[2];
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;

@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
                                                       const uint2* __restrict__ entries,
                                                       const float2* __restrict__ denc /*[L][n]*/,
                                                       float* __restrict__ dtable, int64_t part_stride,
-                                                      int zeroed, const float* __restrict__ f0tab, int n0,
-                                                      uint32_t hw, float inv_hw) {
+                                                      int n_tables, int zeroed, const float* __restrict__ f0tab,
+                                                      int n0, uint32_t hw, float inv_hw) {
   constexpr int NS = PAIR ? 4 : 2;                     // sums per run: (even.x, even.y, odd.x, odd.y) or (x, y)
   __shared__ __attribute__((aligned(16))) float accA[2 * SLOTS_PER_ITEM];  // plain stores: one per run
   __shared__ __attribute__((aligned(16))) float accB[2 * SLOTS_PER_ITEM];  // float atomics: the leftovers
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
     }
   }
   __syncthreads();
-  float* __restrict__ out = dtable + (size_t)part * part_stride + (size_t)it.s0 * 2;
+  float* __restrict__ out = dtable + (size_t)(part % (uint32_t)n_tables) * part_stride + (size_t)it.s0 * 2;
   if (it.part_shared >> 16) {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
       const float v = accA[i] + accB[i];
@@ -375,7 +375,9 @@ struct CsrPlan {
   int dims = 0;
   Levels lv{};
   int nM = 0, H = 0, W = 0;
-  int n_parts = 1;
+  int n_parts = 1;               // point ranges
+  int n_tables = 1;              // partial gradient tables = parts per ROUND; part q writes table q % n_tables
+  std::vector<std::pair<uint32_t, uint32_t>> rounds;  // (first item, item count) of every round = one launch
   int64_t part_size = 0;
   const float* axes[3] = {nullptr, nullptr, nullptr};
   int32_t axn[3] = {0, 0, 0};
@@ -487,21 +489,31 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   // that part's item list.  NP must divide 8.  (Part-major order - all XCDs on one part at a time, which
   // would allow pipelining the MLP backward of part k+1 under the encode backward of part k - costs
   // 0.68 ms instead of 0.59 ms: every XCD then pulls every part's dL/denc slices through its L2.)
+  // Rounds: more than 8 parts (a level slice of dL/denc per part has to stay near 2 MB, an XCD's L2 share) or
+  // fewer tables than parts (op-level plans: ONE table) run as n_parts / n_tables launches of n_tables parts
+  // each; the first overwrites its tiles (solver mode), the following ones add to them - a (table, slot block)
+  // pair has one owner per launch and launches are stream-ordered.
+  const int NT = pl->n_tables, R = NP / NT;
   std::vector<BwdItem> items;
-  if (NP == 1) {
-    items = per_part[0];
-  } else {
-    const int xcds_per_part = 8 / NP;
-    size_t rounds = 0;
-    for (int q = 0; q < NP; ++q) rounds = std::max(rounds, (per_part[q].size() + xcds_per_part - 1) / xcds_per_part);
-    items.assign(rounds * 8, BwdItem{0, 0, 0, 0, 0, 0, 0, 0});
-    for (int x = 0; x < 8; ++x) {
-      const int q = x % NP, lane = x / NP;
-      for (size_t k = 0; k < rounds; ++k) {
-        const size_t j = k * xcds_per_part + lane;
-        if (j < per_part[q].size()) items[k * 8 + x] = per_part[q][j];
+  for (int r = 0; r < R; ++r) {
+    const size_t begin = items.size();
+    if (NT == 1) {
+      items.insert(items.end(), per_part[r].begin(), per_part[r].end());
+    } else {
+      const int xcds_per_part = 8 / NT;
+      size_t steps = 0;
+      for (int j = 0; j < NT; ++j)
+        steps = std::max(steps, (per_part[r * NT + j].size() + xcds_per_part - 1) / xcds_per_part);
+      items.resize(begin + steps * 8, BwdItem{0, 0, 0, 0, 0, 0, 0, 0});
+      for (int x = 0; x < 8; ++x) {
+        const int q = r * NT + x % NT, lane = x / NT;
+        for (size_t k = 0; k < steps; ++k) {
+          const size_t j = k * xcds_per_part + lane;
+          if (j < per_part[q].size()) items[begin + k * 8 + x] = per_part[q][j];
+        }
       }
     }
+    pl->rounds.emplace_back((uint32_t)begin, (uint32_t)(items.size() - begin));
   }
   // final (padded, transposed) positions
   uint64_t total = 0;
@@ -530,8 +542,10 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
 
 // axes: device pointers, only read while the plan is built.
 int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* axes, const int32_t* axn,
-                   int n_parts, CsrPlan** out, hipStream_t st) {
-  IMMOCO_REQUIRE(n_parts == 1 || n_parts == 2 || n_parts == 4 || n_parts == 8, "csr plan: n_parts must divide 8");
+                   int n_parts, int n_tables, CsrPlan** out, hipStream_t st) {
+  IMMOCO_REQUIRE(n_parts >= 1 && n_parts <= 256 && (n_parts & (n_parts - 1)) == 0, "csr plan: n_parts must be a power of two <= 256");
+  IMMOCO_REQUIRE((n_tables == 1 || n_tables == 2 || n_tables == 4 || n_tables == 8) && n_tables <= n_parts,
+                 "csr plan: n_tables must divide 8 and not exceed n_parts");
   const int64_t n = (int64_t)nM * H * W;
   const int64_t part_size = cdiv(n, n_parts);
   IMMOCO_REQUIRE(part_size <= (1ll << (32 - SLOT_BITS)),
@@ -545,6 +559,7 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
   pl->H = H;
   pl->W = W;
   pl->n_parts = n_parts;
+  pl->n_tables = n_tables;
   pl->part_size = part_size;
   for (int d = 0; d < lv.dims; ++d) {
     pl->axes[d] = axes[d];
@@ -562,6 +577,14 @@ int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* a
 int64_t csr_plan_bytes(const CsrPlan* p) { return p ? p->bytes : 0; }
 int64_t csr_plan_entries(const CsrPlan* p) { return p ? (int64_t)p->n_entries : 0; }
 int csr_plan_parts(const CsrPlan* p) { return p ? p->n_parts : 1; }
+int csr_plan_tables(const CsrPlan* p) { return p ? p->n_tables : 1; }
+// parts for a lattice of n points: one level slice of dL/denc (8 B per point) per part ~ 2 MB
+int csr_auto_parts(int64_t n_points) {
+  const int64_t slice = n_points * 8;
+  int parts = 1;
+  while (parts < 256 && slice > (int64_t)parts * (2 << 20)) parts *= 2;
+  return parts;
+}
 const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n) {
   *n = p ? p->n_touched : 0;
   return p ? p->touched : nullptr;
@@ -571,19 +594,23 @@ const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n) {
 // that the buffers hold zeros or stale values of the same plan (plain stores); otherwise the
 // results are accumulated.
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride, int zeroed,
-                   hipStream_t st, int occ_waves) {
+                   hipStream_t st) {
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
   const uint32_t hw = (uint32_t)pl->H * (uint32_t)pl->W;
+  for (size_t r = 0; r < pl->rounds.size(); ++r) {
+    const uint32_t first = pl->rounds[r].first, cnt = pl->rounds[r].second;
+    if (cnt == 0) continue;
+    const int z = r == 0 ? zeroed : 0;  // later rounds add to the tiles the first one has written
 #define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
-  csr_bwd_kernel<D, PAIR><<<pl->n_items, 256, occupancy_cap_lds(occ_waves, 34 * 1024), st>>>(                    \
-                                                       n, pl->part_size, pl->items, pl->entries,                 \
+  csr_bwd_kernel<D, PAIR><<<cnt, 256, 0, st>>>(n, pl->part_size, pl->items + first, pl->entries,                 \
                                                        (const float2*)denc_level_major, dtable, part_stride,     \
-                                                       zeroed, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw)
-  if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);
-  else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false);
-  else IMMOCO_CSR_BWD(2, false);
+                                                       pl->n_tables, z, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw)
+    if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);
+    else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false);
+    else IMMOCO_CSR_BWD(2, false);
 #undef IMMOCO_CSR_BWD
+  }
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
@@ -613,7 +640,9 @@ extern "C" int immoco_grid_plan_create(const immoco_grid_cfg* cfg, int32_t nM, i
     axn[0] = W; axn[1] = H; axn[2] = 0;    // (x = col, y = row)
   }
   CsrPlan* pl = nullptr;
-  if ((rc = csr_plan_build(lv, nM, H, W, axes, axn, 1, &pl, as_stream(stream)))) return rc;
+  // one output table; large lattices are walked in rounds of ~2 MB of dL/denc per level (csr_auto_parts)
+  if ((rc = csr_plan_build(lv, nM, H, W, axes, axn, csr_auto_parts((int64_t)nM * H * W), 1, &pl, as_stream(stream))))
+    return rc;
   *out = new immoco_grid_plan{pl};
   return IMMOCO_OK;
 }

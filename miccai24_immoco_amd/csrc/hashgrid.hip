@@ -9,6 +9,9 @@
 // always samples linspace(-1,1,.) lattices, immoco.py:48-53,72-80).
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace immoco {
@@ -72,6 +75,15 @@ __device__ __forceinline__ void load_coords(const float* __restrict__ coords, co
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = coords[p * D + d];
   }
+}
+
+// A/B switch (environment, read once): IMMOCO_ENC_STORE=plain keeps the streamed encoding in L2
+static int enc_store_sc1() {
+  static const int v = [] {
+    const char* e = getenv("IMMOCO_ENC_STORE");
+    return (e && strcmp(e, "plain") == 0) ? 0 : 1;
+  }();
+  return v;
 }
 
 // TAB = float2: fp32 table; TAB = __half2: fp16 shadow of the table ("fp16 hash-grid features",
@@ -149,15 +161,33 @@ template <int D, bool LAT, typename TAB = float2>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const float* __restrict__ coords,
                                                            Lattice lat, int64_t n,
                                                            const TAB* __restrict__ table,
-                                                           float* __restrict__ enc, int64_t ps, int64_t ls) {
+                                                           float* __restrict__ enc, int64_t ps, int64_t ls,
+                                                           int store_sc1) {
   const int l = blockIdx.y;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   float x[D];
   load_coords<D, LAT>(coords, lat, p, x);
-  *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = encode_point_level<D, TAB>(lv, l, x, table);
+  const float2 e = encode_point_level<D, TAB>(lv, l, x, table);
+  // The encoding streams out (131 MB per launch at 320x320x10) while the gathers want the 4 MB level slice of
+  // the table to STAY in the XCD's 4 MB L2: an agent-scope relaxed store is emitted as `global_store ... sc1`,
+  // which writes through and drops the line from L2 instead of keeping it (MI355X_MICROARCH.md, store flavours).
+  if (store_sc1) {
+    union { float2 f; uint64_t u; } cv;
+    cv.f = e;
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(enc + p * ps + (int64_t)l * ls), cv.u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = e;
+  }
 }
 
+// Measured dead end (round 2): an XCD-scheduled launch - workgroup w runs on XCD w % 8, XCD x encodes ALL points
+// of "its" hashed level (the first eight hashed levels, one each, so that a 4 MB table slice is fetched by ONE L2
+// instead of eight) plus an eighth of the points of every other level - cut the compulsory L2 misses (3.6 M of
+// the 43.2 M L1->L2 requests per launch, rocprofv3 TCP_TCC_READ_REQ / TCC_MISS) and changed nothing: 0.279 vs
+// 0.274 ms.  Neither L2 misses nor distinct lines per instruction (lane-paired corners, above) are what the
+// forward waits for; it runs at 157 G L2 requests/s against the probe's 259.
 // Measured dead end: a "level sweep" launch (one workgroup keeps 512 points and walks the 16 levels, meant
 // to keep a single 4 MB level slice live per XCD L2) ran at 0.81 ms instead of 0.36 ms: workgroups drift
 // apart and soon touch 3-4 level slices at once, and immoco_probe_gather shows the price - random 16-byte
@@ -202,20 +232,19 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(Levels lv, con
 }
 
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
-                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st, int occ_waves) {
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st) {
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "encoding strides must be even (float2 stores)");
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   Lattice L{};
   if (lat) L = *lat;
   const float2* t = reinterpret_cast<const float2*>(table);
-  const unsigned lds = occupancy_cap_lds(occ_waves, 0);
   if (lv.dims == 2) {
-    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
-    else hashgrid_fwd_kernel<2, false><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
+    else hashgrid_fwd_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
   } else {
-    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
-    else hashgrid_fwd_kernel<3, false><<<grid, block, lds, st>>>(lv, coords, L, n, t, enc, ps, ls);
+    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
+    else hashgrid_fwd_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
   }
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
@@ -223,13 +252,12 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
 
 // forward from the fp16 shadow table (lattice mode only: the solver's path)
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
-                             int64_t ps, int64_t ls, hipStream_t st, int occ_waves) {
+                             int64_t ps, int64_t ls, hipStream_t st) {
   if (n == 0) return IMMOCO_OK;
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   const __half2* t = reinterpret_cast<const __half2*>(table_half2);
-  const unsigned lds = occupancy_cap_lds(occ_waves, 0);
-  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, lds, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
-  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, lds, st>>>(lv, nullptr, lat, n, t, enc, ps, ls);
+  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());
+  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
@@ -356,10 +384,10 @@ extern "C" int immoco_hashgrid_fwd_f16(const immoco_grid_cfg* cfg, const float* 
   Lattice none{};
   if (lv.dims == 2)
     hashgrid_fwd_kernel<2, false, __half2><<<grid, block, 0, as_stream(stream)>>>(lv, coords, none, n, t, enc,
-                                                                                 enc_point_stride, enc_level_stride);
+                                                                                 enc_point_stride, enc_level_stride, enc_store_sc1());
   else
     hashgrid_fwd_kernel<3, false, __half2><<<grid, block, 0, as_stream(stream)>>>(lv, coords, none, n, t, enc,
-                                                                                 enc_point_stride, enc_level_stride);
+                                                                                 enc_point_stride, enc_level_stride, enc_store_sc1());
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

@@ -12,17 +12,11 @@ struct Lattice {
 };
 
 // hashgrid.hip
-// occ_waves: occupancy cap in waves per SIMD (3..8; 0 = none), realised with unused dynamic LDS, so that
-// kernels of another slice in flight find free wave slots / registers beside this gather
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
-                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st, int occ_waves = 0);
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st);
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
-                             int64_t ps, int64_t ls, hipStream_t st, int occ_waves = 0);
-static inline unsigned occupancy_cap_lds(int occ_waves, unsigned static_lds) {
-  if (occ_waves < 3 || occ_waves > 8) return 0u;   // (2 would need > 64 KB of LDS per workgroup)
-  const unsigned per_wg = 160u * 1024u / (unsigned)occ_waves;  // a 256-thread workgroup = one wave per SIMD
-  return per_wg > static_lds + 512u ? per_wg - static_lds - 512u : 0u;
-}
+                             int64_t ps, int64_t ls, hipStream_t st);
+
 int launch_f32_to_half(const float* in, void* out_half, int64_t n, hipStream_t st);
 int launch_hashgrid_bwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
                         const float* denc, int64_t ps, int64_t ls, float* dtable, hipStream_t st);
@@ -97,12 +91,15 @@ int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float*
 // are cleared after use.
 int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n_w,
                        const uint2* blocks, uint32_t n_blocks, const float* sched, const int32_t* iter_dev,
-                       float beta1, float beta2, float eps, hipStream_t st, void* shadow = nullptr);
+                       float beta1, float beta2, float eps, hipStream_t st, void* shadow = nullptr,
+                       int iter_off = 0);  // schedule index = *iter_dev + iter_off
 
 // csr.hip — atomic-free hash-grid backward for fixed lattices
 struct CsrPlan;
 int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* axes, const int32_t* axn,
-                   int n_parts, CsrPlan** out, hipStream_t st);
+                   int n_parts, int n_tables, CsrPlan** out, hipStream_t st);
+int csr_auto_parts(int64_t n_points);
+int csr_plan_tables(const CsrPlan* p);
 void csr_plan_free(CsrPlan* p);
 int64_t csr_plan_bytes(const CsrPlan* p);
 int64_t csr_plan_entries(const CsrPlan* p);
@@ -111,7 +108,7 @@ int csr_plan_parts(const CsrPlan* p);
 // flushed with atomics and have to be cleared by the consumer, unlisted blocks never get a gradient
 const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n);
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,
-                   int zeroed, hipStream_t st, int occ_waves = 0);
+                   int zeroed, hipStream_t st);
 
 // masks.hip
 int launch_extract_groups(const uint8_t* lines, int n, int32_t* col_group, int32_t* n_groups, hipStream_t st);

@@ -82,9 +82,10 @@ __global__ __launch_bounds__(256) void adam_blocks_kernel(float* __restrict__ p,
                                                           float* __restrict__ v, int64_t n_w4, uint32_t n_wblocks,
                                                           const uint2* __restrict__ blocks,
                                                           const float* __restrict__ sched,
-                                                          const int32_t* __restrict__ iter_dev, float b1, float b2,
-                                                          float eps, __half* __restrict__ shadow) {
-  const int it = *iter_dev;
+                                                          const int32_t* __restrict__ iter_dev, int iter_off,
+                                                          float b1, float b2, float eps,
+                                                          __half* __restrict__ shadow) {
+  const int it = *iter_dev + iter_off;   // iter_off = -1: the deferred update of the PREVIOUS iteration (solver.hip)
   const float step_size = sched[2 * it], bc2_sqrt = sched[2 * it + 1];
   int64_t i0, cnt;
   bool zero;
@@ -157,7 +158,7 @@ int launch_adam_sched(float* p, float* g, int n_gparts, int64_t g_stride, float*
 
 int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float* m, float* v, int64_t n_w,
                        const uint2* blocks, uint32_t n_blocks, const float* sched, const int32_t* iter_dev,
-                       float beta1, float beta2, float eps, hipStream_t st, void* shadow) {
+                       float beta1, float beta2, float eps, hipStream_t st, void* shadow, int iter_off) {
   IMMOCO_REQUIRE((n_w % 4) == 0, "adam: the MLP weight count must be a multiple of 4 (got %lld)", (long long)n_w);
   IMMOCO_REQUIRE(n_gparts >= 1 && (g_stride % 4) == 0, "adam: partial gradient stride must be a multiple of 4");
   IMMOCO_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
@@ -165,7 +166,7 @@ int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float
   const uint32_t n_wblocks = (uint32_t)cdiv(n_w / 4, 1024);
   if (n_wblocks + n_blocks == 0) return IMMOCO_OK;
   adam_blocks_kernel<<<n_wblocks + n_blocks, 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n_w / 4, n_wblocks, blocks,
-                                                          sched, iter_dev, beta1, beta2, eps,
+                                                          sched, iter_dev, iter_off, beta1, beta2, eps,
                                                           reinterpret_cast<__half*>(shadow));
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;

@@ -26,6 +26,7 @@ struct Step {
   const char* name;
   std::function<int(hipStream_t)> run;
   int branch = 0;
+  int group = 2;  // 0 image forward, 1 motion forward, 2 serial middle, 3 motion backward, 4 image backward, 5 tick
 };
 
 }  // namespace immoco
@@ -47,7 +48,8 @@ struct immoco_solver {
   uint16_t *shadow_img = nullptr, *shadow_mot = nullptr;  // fp16 shadows of the tables (cfg.table_fp16)
   CsrPlan *plan_img = nullptr, *plan_mot = nullptr;
   bool lattice_set = false;
-  int mot_parts = 1;            // partial gradient tables of the motion INR
+  int mot_parts = 1;            // point-range parts of the motion grid's transposed index
+  int mot_tables = 1;           // partial gradient tables of the motion INR (= parts per launch, <= 8)
   int64_t mot_gstride = 0;      // floats between them (n_params_mot rounded up to 4)
   int32_t* iter_dev = nullptr;
   int32_t sched_cap = 0;
@@ -60,7 +62,8 @@ struct immoco_solver {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
   bool marked = false;
   // graph cache: valid while the captured pointers stay the same
-  hipGraphExec_t gexec = nullptr;
+  hipGraphExec_t gexec = nullptr;    // classic order, or the FIRST iteration of the pipelined order
+  hipGraphExec_t gexec2 = nullptr;   // steady-state iteration of the pipelined order
   std::vector<const void*> gkey;
   int graph_active = 0;
   // phase timing of the last profile call
@@ -92,7 +95,7 @@ struct Bind {
 };
 
 // The per-iteration kernel sequence (immoco.py:166-175).
-std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
+std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward, int img_adam_off = 0) {
   const immoco_solver_cfg& c = s->cfg;
   const int H = c.H, W = c.W, nM = c.nM;
   const int64_t P = s->P, NP = s->NP;
@@ -131,10 +134,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   if (nM > 0) {
     st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
                     if (s->cfg.table_fp16)
-                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, 2, 2 * NP, q,
-                                                      s->cfg.gather_waves);
-                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q,
-                                               s->cfg.gather_waves);
+                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, 2, 2 * NP, q);
+                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
                   }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
@@ -168,7 +169,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                         // gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
                     if (s->plan_mot)
-                      return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q, s->cfg.gather_waves);
+                      return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q);
                     return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
                   }, 1});
   }
@@ -189,7 +190,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     if (s->plan_mot) {
                       uint32_t nb = 0;
                       const uint2* blocks = csr_plan_touched(s->plan_mot, &nb);
-                      return launch_adam_blocks(b.p_mot, s->grad_mot, s->mot_parts, s->mot_gstride, b.a_mot,
+                      return launch_adam_blocks(b.p_mot, s->grad_mot, s->mot_tables, s->mot_gstride, b.a_mot,
                                                 b.a_mot + s->n_params_mot, s->n_w_mot, blocks, nb, s->sched,
                                                 s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
                                                 s->cfg.table_fp16 ? s->shadow_mot : nullptr);
@@ -205,7 +206,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     const uint2* blocks = csr_plan_touched(s->plan_img, &nb);
                     return launch_adam_blocks(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
                                               s->n_w_img, blocks, nb, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
-                                              s->cfg.table_fp16 ? s->shadow_img : nullptr);
+                                              s->cfg.table_fp16 ? s->shadow_img : nullptr, img_adam_off);
                   }
                   return launch_adam_sched(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
                                            s->n_params_img, s->n_params_img, s->sched, s->iter_dev, 0.9f, 0.999f,
@@ -216,22 +217,74 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   IMMOCO_LAUNCH_CHECK();
                   return IMMOCO_OK;
                 }});
+  for (Step& x : st) {
+    const std::string n = x.name;
+    x.group = (n == "image_encode_fwd" || n == "image_mlp_fwd" || n == "image_to_fft_slot") ? 0
+              : (n == "motion_encode_fwd" || n == "motion_mlp_fwd")                             ? 1
+              : (n == "motion_encode_bwd" || n == "adam_motion")                                ? 3
+              : (n == "image_mlp_bwd" || n == "image_encode_bwd" || n == "adam_image")         ? 4
+              : n == "tick"                                                                     ? 5
+                                                                                                : 2;
+  }
   return st;
+}
+
+// Software pipelining ACROSS iterations (round 2).  In the classic order [image fwd || motion fwd] -> middle ->
+// [motion bwd || image bwd] the image chain's backward is the tail of the iteration: its MFMA kernel needs a
+// whole SIMD's registers and starves beside the motion grid's encode backward (0.62 ms instead of 0.14), so the
+// iteration ends ~0.08 ms after the motion chain has finished.  Nothing of iteration k+1's MOTION forward depends
+// on the image parameters, so the image backward of iteration k (MLP backward, encode backward, Adam) is deferred
+// to the start of iteration k+1, in front of that iteration's image forward and beside its motion encode forward:
+//   first:   [image fwd(0) || motion fwd(0)] -> middle(0) -> motion bwd(0) -> tick
+//   steady:  [image bwd(k-1), image fwd(k) || motion fwd(k)] -> middle(k) -> motion bwd(k) -> tick
+//   last:    image bwd(n-1)
+// Every parameter sees the same updates in the same order as before (the deferred Adam reads the schedule of its
+// own iteration: iter_off = -1); only the launch order changes.
+// MEASURED (MI355X, 320x320x10): 1.446 ms per iteration instead of 1.351 - the deferred MFMA kernel starves beside
+// the motion encode FORWARD just as it did beside the backward (that gather holds all 8 wave slots of every SIMD),
+// and now it sits in front of the image forward that the warp waits for.  Kept behind IMMOCO_PIPELINE=1 as an A/B
+// switch; the default is the classic order.
+enum class Order { Classic, First, Steady, Epilogue };
+
+std::vector<Step> arrange(const std::vector<Step>& all, Order o) {
+  if (o == Order::Classic) return all;
+  std::vector<Step> out;
+  auto take = [&](int group, int branch) {
+    for (const Step& x : all)
+      if (x.group == group) {
+        Step y = x;
+        y.branch = branch;
+        out.push_back(y);
+      }
+  };
+  if (o == Order::Epilogue) {
+    take(4, 0);
+    return out;
+  }
+  if (o == Order::Steady) take(4, 2);
+  take(0, 2);
+  take(1, 1);
+  take(2, 0);
+  take(3, 0);
+  take(5, 0);
+  return out;
 }
 
 // A graph executable must outlive its queued launches: a solve that needs a new capture (other slice, other
 // buffers) parks the old one behind an event on the stream instead of destroying it under the GPU's feet.
 void retire_graph(immoco_solver* s) {
-  if (!s->gexec) return;
-  hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, s->stream) == hipSuccess) {
-    s->retired.emplace_back(s->gexec, ev);
-  } else {  // fall back to draining the stream
-    (void)hipStreamSynchronize(s->stream);
-    hipGraphExecDestroy(s->gexec);
-    if (ev) hipEventDestroy(ev);
+  for (hipGraphExec_t* g : {&s->gexec, &s->gexec2}) {
+    if (!*g) continue;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, s->stream) == hipSuccess) {
+      s->retired.emplace_back(*g, ev);
+    } else {  // fall back to draining the stream
+      (void)hipStreamSynchronize(s->stream);
+      hipGraphExecDestroy(*g);
+      if (ev) hipEventDestroy(ev);
+    }
+    *g = nullptr;
   }
-  s->gexec = nullptr;
 }
 void sweep_retired(immoco_solver* s, bool wait) {
   for (size_t i = 0; i < s->retired.size();) {
@@ -369,14 +422,14 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   A(kin_t, 2 * s->P)
   A(fft_t, 2 * s->P * (cfg->nM + 1))
   A(grad_img, s->n_params_img)
-  // partial gradient tables of the motion grid: as many point ranges as it takes to bring one level slice
-  // of dL/denc (8 B per point) down to ~2 MB per XCD L2 (csr.hip), at most 8: 320x320x10 -> 4, 640x640x20 -> 8
-  // (5.8 instead of 8.1 ms for that kernel), small lattices -> 1 (no partial tables for Adam to sum)
-  const int64_t slice_bytes = (int64_t)cfg->nM * cfg->H * cfg->W * 8;
-  const int auto_parts = slice_bytes <= (2 << 20) ? 1 : slice_bytes <= (4 << 20) ? 2 : slice_bytes <= (8 << 20) ? 4 : 8;
+  // point ranges of the motion grid's transposed index: as many as it takes to bring one level slice of dL/denc
+  // (8 B per point) down to ~2 MB per XCD L2 (csr.hip): 320x320x10 -> 4, 640x640x20 -> 32; at most 8 of them run
+  // in one launch, each into its own partial gradient table (summed by Adam), further ones in following launches
+  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W);
   s->mot_parts = cfg->atomic_scatter ? 1 : (cfg->grad_parts > 0 ? cfg->grad_parts : auto_parts);
+  s->mot_tables = std::min(s->mot_parts, 8);
   s->mot_gstride = (s->n_params_mot + 3) / 4 * 4;
-  A(grad_mot, s->mot_gstride * s->mot_parts)
+  A(grad_mot, s->mot_gstride * s->mot_tables)
   A(iter_dev, 4)
   if (cfg->table_fp16) {
     A(shadow_img, s->n_params_img - s->n_w_img)
@@ -395,7 +448,7 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(s->grad_img, 0, (size_t)s->n_params_img * 4);
-  if (e == hipSuccess) e = hipMemset(s->grad_mot, 0, (size_t)s->mot_gstride * s->mot_parts * 4);
+  if (e == hipSuccess) e = hipMemset(s->grad_mot, 0, (size_t)s->mot_gstride * s->mot_tables * 4);
   if (e != hipSuccess) {
     set_error("solver_create: %s", hipGetErrorString(e));
     immoco_solver_destroy(s);
@@ -419,6 +472,7 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->side) (void)hipStreamSynchronize(s->side);
   if (s->gexec) hipGraphExecDestroy(s->gexec);
+  if (s->gexec2) hipGraphExecDestroy(s->gexec2);
   sweep_retired(s, true);
   if (s->parent) {  // a lane borrows lattices and plans from its parent
     s->plan_img = s->plan_mot = nullptr;
@@ -477,11 +531,13 @@ extern "C" int immoco_solver_set_lattice(immoco_solver_t s, const float* xs, con
     int rc;
     const float* ax2[3] = {s->xs, s->ys, nullptr};
     const int32_t n2[3] = {c.W, c.H, 0};
-    if ((rc = csr_plan_build(s->lv_img, 1, c.H, c.W, ax2, n2, 1, &s->plan_img, s->stream))) return rc;
+    if ((rc = csr_plan_build(s->lv_img, 1, c.H, c.W, ax2, n2, 1, 1, &s->plan_img, s->stream))) return rc;
     if (c.nM > 0) {
       const float* ax3[3] = {s->ms, s->ys, s->xs};
       const int32_t n3[3] = {c.nM, c.H, c.W};
-      if ((rc = csr_plan_build(s->lv_mot, c.nM, c.H, c.W, ax3, n3, s->mot_parts, &s->plan_mot, s->stream))) return rc;
+      if ((rc = csr_plan_build(s->lv_mot, c.nM, c.H, c.W, ax3, n3, s->mot_parts, s->mot_tables, &s->plan_mot,
+                               s->stream)))
+        return rc;
     }
   }
   s->lattice_set = true;
@@ -529,36 +585,46 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
   if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
   Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
-  std::vector<Step> steps = build_steps(s, b, true);
+  // pipelined order (image backward of iteration k beside the motion forward of iteration k+1, see arrange()):
+  // an A/B switch, OFF by default - measured 1.446 instead of 1.351 ms per iteration at 320x320x10
+  static const bool want_pipeline = getenv("IMMOCO_PIPELINE") != nullptr;
+  const bool pipelined = want_pipeline && s->cfg.nM > 0 && !s->cfg.serial_chains && s->plan_img && s->plan_mot;
+  const std::vector<Step> all = build_steps(s, b, true, pipelined ? -1 : 0);
+  const std::vector<Step> first = arrange(all, pipelined ? Order::First : Order::Classic);
+  const std::vector<Step> steady = pipelined ? arrange(all, Order::Steady) : first;
+  auto run_list = [&](const std::vector<Step>& l) { return s->cfg.serial_chains ? run_steps(l, q) : run_steps_forked(s, l, q); };
+  auto capture = [&](const std::vector<Step>& l, hipGraphExec_t* out) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal) != hipSuccess) return;
+    const int r = run_list(l);
+    const hipError_t e2 = hipStreamEndCapture(q, &graph);
+    if (r == IMMOCO_OK && e2 == hipSuccess && graph)
+      if (hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
+    if (graph) hipGraphDestroy(graph);
+  };
   s->graph_active = 0;
   if (s->cfg.use_graph) {
     std::vector<const void*> key = {kspace_in,  col_group,   params_image, params_motion,
-                                    adam_image, adam_motion, loss_hist,    s->sched};
+                                    adam_image, adam_motion, loss_hist,    s->sched, pipelined ? s : nullptr};
     sweep_retired(s, false);
-    if (!s->gexec || key != s->gkey) {
+    if (!s->gexec || key != s->gkey || (pipelined && iters > 1 && !s->gexec2)) {
       retire_graph(s);
-      hipGraph_t graph = nullptr;
-      hipError_t e = hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal);
-      if (e == hipSuccess) {
-        rc = s->cfg.serial_chains ? run_steps(steps, q) : run_steps_forked(s, steps, q);
-        hipError_t e2 = hipStreamEndCapture(q, &graph);
-        if (rc == IMMOCO_OK && e2 == hipSuccess && graph) {
-          if (hipGraphInstantiate(&s->gexec, graph, nullptr, nullptr, 0) != hipSuccess) s->gexec = nullptr;
-        }
-        if (graph) hipGraphDestroy(graph);
-      }
+      capture(first, &s->gexec);
+      if (pipelined && iters > 1 && s->gexec) capture(steady, &s->gexec2);
       (void)hipGetLastError();
       s->gkey = key;
     }
-    s->graph_active = s->gexec != nullptr;
+    s->graph_active = s->gexec != nullptr && (!pipelined || iters == 1 || s->gexec2 != nullptr);
   }
   for (int j = 0; j < iters; ++j) {
+    const bool st = pipelined && j > 0;
     if (s->graph_active) {
-      IMMOCO_CHECK_HIP(hipGraphLaunch(s->gexec, q));
-    } else if ((rc = s->cfg.serial_chains ? run_steps(steps, q) : run_steps_forked(s, steps, q))) {
+      IMMOCO_CHECK_HIP(hipGraphLaunch(st ? s->gexec2 : s->gexec, q));
+    } else if ((rc = run_list(st ? steady : first))) {
       return rc;
     }
   }
+  if (pipelined && (rc = run_steps(arrange(all, Order::Epilogue), q))) return rc;   // image backward of the last iteration
   // tensors of the LAST forward pass (immoco.py:203-206)
   if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
   if (out_kspace && (rc = launch_transpose_c64(s->kout, out_kspace, s->cfg.W, s->cfg.H, q))) return rc;

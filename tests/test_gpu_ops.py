@@ -598,7 +598,9 @@ def test_teacher_forced_state_c2_shape(env):
     from oracle import synth_cpu
     s = synth_cpu.make_slice(320, 320, 10, 1)
     masks = orc.extract_movement_groups(s["lines"], make_list=True)
-    rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, 5)
+    import os
+    K = int(os.environ.get("IMMOCO_TF_K", "5"))       # diagnostic: IMMOCO_TF_K=200 hands over a late state (minutes of CPU)
+    rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, K)
     # measured: gradient rel. L2 6e-7 (image) / 7e-6 (motion), largest update difference 4.0e-6 = 4e-4 * lr
     for name in ("img", "mot"):
         r = rep[name]
@@ -780,17 +782,43 @@ def test_grid_plan_refuses_oversized_lattice(env):
     a lattice beyond that is refused with a message instead of overflowing silently."""
     pkg, L, orc = env
     cfg = L.grid_cfg(2, pkg.encoding_config)
-    H = W = 1536                                    # 2.36 M points > 2^21 in the single part of the op-level plan
+    H = W = 8200                                    # 67.2 M points x 16 levels x 4 corners > 2^32 entries
     xs, ys = torch.linspace(-1, 1, W, device="cuda"), torch.linspace(-1, 1, H, device="cuda")
     plan = C.c_void_p()
     rc = L.lib().immoco_grid_plan_create(C.byref(cfg), 1, H, W, L.ptr(xs), L.ptr(ys), L.ptr(xs), C.byref(plan),
                                          L.stream_ptr())
     assert rc != 0 and not plan.value
-    assert "points per part" in L.last_error()
-    # the solver picks more parts for large lattices, and refuses what does not fit either way
+    assert "too many entries" in L.last_error()
+    # a part may hold 2^21 points: one part for 256x256x40 = 2.6 M points is refused, the automatic choice works
     from miccai24_immoco_amd.models.immoco import _SolverHandle
-    with pytest.raises(L.ImmocoError):
-        _SolverHandle(torch.device("cuda", 0), 64, 64, 5000)     # 20.5 M points: > 8 parts x 2^21
+    with pytest.raises(L.ImmocoError, match="points per part"):
+        _SolverHandle(torch.device("cuda", 0), 256, 256, 40, grad_parts=1)
+
+
+def test_grid_plan_rounds_large_lattice_vs_atomic(env):
+    """Op-level plan of a lattice that needs several rounds (2.36 M points -> 16 point ranges into ONE table,
+    beyond the 2^21 points a single part can address) == the generic atomic scatter."""
+    pkg, L, orc = env
+    cfg = L.grid_cfg(2, pkg.encoding_config)
+    H = W = 1536
+    xs, ys = torch.linspace(-1, 1, W, device="cuda"), torch.linspace(-1, 1, H, device="cuda")
+    n = H * W
+    g = torch.Generator(device="cuda").manual_seed(5)
+    d_lm = torch.randn(16, n, 2, device="cuda", generator=g)
+    plan = C.c_void_p()
+    st = L.stream_ptr()
+    L.check(L.lib().immoco_grid_plan_create(C.byref(cfg), 1, H, W, L.ptr(xs), L.ptr(ys), L.ptr(xs), C.byref(plan), st))
+    try:
+        n_entries = int(L.geometry(cfg).offset[16])
+        dt = torch.zeros(n_entries, 2, device="cuda")
+        L.check(L.lib().immoco_grid_plan_bwd(plan, L.ptr(d_lm), L.ptr(dt), st))
+        coords = F.affine_grid(torch.eye(2, 3, device="cuda").unsqueeze(0), torch.Size((1, 1, H, W)),
+                               align_corners=True).view(-1, 2).contiguous()
+        da = torch.zeros_like(dt)
+        L.check(L.lib().immoco_hashgrid_bwd(C.byref(cfg), L.ptr(coords), n, L.ptr(d_lm), 2, 2 * n, L.ptr(da), st))
+        assert (dt - da).abs().max().item() <= 2e-5 * da.abs().max().item()
+    finally:
+        L.lib().immoco_grid_plan_destroy(plan)
 
 
 def test_tcnn_module_backward_uses_the_lattice_plan(env):
@@ -827,6 +855,50 @@ def test_tcnn_module_backward_uses_the_lattice_plan(env):
         a.params.grad = None
         a(xp).square().sum().backward()
         assert a._plan is None and bool(torch.isfinite(a.params.grad).all())
+
+
+def test_caller_driven_loop_within_2x_of_fused_solver(env, golden):
+    """INTEGRATION.md promises that a maintainer may keep the reference's own Python loop (immoco.py:164-175) on
+    the module API.  With the lattice plan behind NetworkWithInputEncoding.backward that loop runs within 2x of
+    the fused solver at config C2 (measured 1.59x: 2.16 vs 1.37 ms per iteration; round 1, with the generic atomic
+    scatter in the backward: ~10x) - and follows the same trajectory."""
+    import time
+    pkg, L, orc = env
+    k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
+    model = pkg.IMMoCo(masks)
+    opt = torch.optim.Adam([{"params": model.motion_inr.parameters(), "lr": 1e-2},
+                            {"params": model.image_inr.parameters(), "lr": 1e-2}])
+    ge = pkg.GradientEntropyLoss()
+    hist = []
+
+    def one():
+        opt.zero_grad()
+        kf, ip = model()
+        loss = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(kin)) + ge(ip).mul(1e-2)
+        loss.backward()
+        opt.step()
+        hist.append(loss.detach())
+
+    n = 40
+    for _ in range(8):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    torch.cuda.synchronize()
+    ms_loop = (time.perf_counter() - t0) / n * 1e3
+    assert model.motion_inr._plan is not None and model.image_inr._plan is not None
+    _, _, l0 = pkg.imcoco_motion_correction(k, masks, iters=48, return_loss=True)     # also warms the solver up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pkg.imcoco_motion_correction(k, masks, iters=n)
+    torch.cuda.synchronize()
+    ms_fused = (time.perf_counter() - t0) / n * 1e3
+    print(f"caller-driven loop {ms_loop:.3f} ms/iteration, fused solver {ms_fused:.3f} ms/iteration, ratio {ms_loop / ms_fused:.2f}")
+    assert ms_loop <= 2.0 * ms_fused, (ms_loop, ms_fused)
+    lh = torch.stack(hist).cpu().numpy()
+    np.testing.assert_allclose(lh[:6], l0.cpu().numpy()[:6], rtol=5e-4)       # same seeds (1337 both INRs), same start
 
 
 def test_solver_csr_vs_atomic_scatter(env, golden):
@@ -909,20 +981,44 @@ def test_solver_no_motion_groups_vs_oracle(env):
     np.testing.assert_allclose(img.cpu().numpy(), ip.detach().numpy(), rtol=0, atol=2e-2 * float(ip.abs().max()))
 
 
-def test_solver_config5_shape_640x640_20_groups(env):
-    """Config 5's shape (8.2 M lattice points, 1.05 G transposed-index entries, fp32): the atomic-free
-    backward, the XCD-partitioned plan and the uint32 entry/offset ranges hold at 8x the points of C2."""
+def test_solver_config5_shape_and_precision_vs_oracle_record(env, golden):
+    """BASELINE config 5 at its OWN shape and precision together: 640x640, 20 motion groups (8.2 M lattice
+    points, 32 point ranges of the transposed index in 4 rounds, 684 M entries), fp16 hash-grid features with fp32
+    master tables + fp32 Adam (table_fp16), against the CPU oracle's recorded first iterations at exactly that
+    configuration (tools/oracle_c5.py -> tests/golden/c5_oracle_fp16.npz; the oracle needs ~10 GB and minutes
+    per iteration there, hence a record).  Also: the atomic-free backward == the generic atomic scatter there."""
     pkg, L, orc = env
     from oracle import synth_cpu
     from miccai24_immoco_amd.models.immoco import get_solver, _SOLVERS
-    s = synth_cpu.make_slice(640, 640, 20, 7)
+    g = golden("c5_oracle_fp16")
+    s = synth_cpu.make_slice(int(g["H"]), int(g["W"]), int(g["n_movements"]), int(g["slice_idx"]))
     masks = pkg.extract_movement_groups(s["lines"].cuda(), make_list=True)
     nM = masks.shape[0]
-    assert nM >= 15
+    assert nM == int(g["n_groups"]) >= 15
+    # the input is regenerated here (3.3 MB as a fixture): same generator, checked against the record's checksums
+    assert abs(float(s["kspace"].abs().double().sum()) - float(g["kspace_abs_sum"])) <= 1e-5 * float(g["kspace_abs_sum"])
     ksp = s["kspace"].cuda()
+    ol = g["loss"].astype(np.float64)
+    n = len(ol)
+    from miccai24_immoco_amd.models.immoco import lambda_schedule
+    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    sol = get_solver("cuda", 640, 640, nM, table_fp16=True)
+    pi, pm = sol.init_params()
+    ai, am = torch.zeros(2 * pi.numel(), device="cuda"), torch.zeros(2 * pm.numel(), device="cuda")
+    kin = ksp / ksp.abs().max() * 16000
+    _, _, lf = sol.solve(kin, masks_to_col_group(masks), pi, pm, ai, am, n, 1e-2, lambda_schedule(3000, 1e-2)[:n],
+                         want_loss=True)
+    lf = lf.cpu().numpy().astype(np.float64)
+    print("C5 fp16 losses: hip", lf.tolist(), "oracle", ol.tolist())
+    np.testing.assert_allclose(lf[:3], ol[:3], rtol=5e-5)
+    np.testing.assert_allclose(lf, ol, rtol=2e-3)
+    ws = sol.workspace_bytes
+    assert ws > 4e9          # the 684 M-entry index alone is 5.5 GB
+    for k in [k for k in _SOLVERS if k[1] == 640]:
+        _SOLVERS.pop(k).close()
+    torch.cuda.empty_cache()
+    # fp32 at the same shape: transposed index == atomic scatter
     _, _, l0 = pkg.imcoco_motion_correction(ksp, masks, iters=12, return_loss=True)
-    ws = get_solver("cuda", 640, 640, nM).workspace_bytes
-    assert ws > 4e9          # the 1.05 G-entry index alone is 4.2 GB
     for k in [k for k in _SOLVERS if k[1] == 640]:
         _SOLVERS.pop(k).close()
     torch.cuda.empty_cache()
@@ -931,7 +1027,9 @@ def test_solver_config5_shape_640x640_20_groups(env):
         _SOLVERS.pop(k).close()
     a, b = l0.cpu().numpy(), l1.cpu().numpy()
     assert np.isfinite(a).all() and a[-1] < a[0]
-    np.testing.assert_allclose(a[:5], b[:5], rtol=1e-4)
+    np.testing.assert_allclose(a[:3], b[:3], rtol=1e-4)
+    np.testing.assert_allclose(a[:5], b[:5], rtol=2e-3)       # two fp32 summation orders: 1.6e-4 apart at iteration 4
+    assert abs(a[0] - lf[0]) <= 1e-2 * a[0] and a[0] != lf[0]        # fp16 features: close to, not equal to, fp32
 
 
 def test_batch_of_slices_independent(env):
@@ -951,61 +1049,87 @@ def test_batch_of_slices_independent(env):
     assert abs(a0[0] - b0[0]) > 1e-3 * a0[0]                    # different slice -> different problem
 
 
-def test_config2_trajectory_vs_cpu_oracle(env, golden):
-    """Config C2 (320x320, 10 groups), 300 iterations, against the CPU oracle's recorded trajectory
-    (tools/oracle_c2.py, 44 min on 4 cores; tests/golden/c2_oracle_slice1_300it.npz).
-    Measured on MI355X (tools/diag_c2.py): identical loss to 4 digits through iteration 5, 0.2 % at
-    10, 0.5 % at 20, then chaos: final loss 0.037..0.045 (oracle 0.038), PSNR 34.9..37.6 dB over 6
-    runs with median 37.1 (oracle 37.15)."""
-    pkg, L, orc = env
-    from oracle import synth_cpu
-    g = golden("c2_oracle_slice1_300it")
-    ol = g["loss"].astype(np.float64)
-    s = synth_cpu.make_slice(320, 320, 10, int(g["slice_idx"]))
-    masks = pkg.extract_movement_groups(s["lines"].cuda(), make_list=True)
-    assert masks.shape[0] == 10
-    ps, finals = [], []
-    for _ in range(5):
-        img, _, loss = pkg.imcoco_motion_correction(s["kspace"].cuda(), masks, iters=300, return_loss=True)
-        lh = loss.cpu().numpy().astype(np.float64)
-        np.testing.assert_allclose(lh[:6], ol[:6], rtol=5e-4)
-        np.testing.assert_allclose(lh[:11], ol[:11], rtol=2e-2)
-        np.testing.assert_allclose(lh[:21], ol[:21], rtol=5e-2)
-        finals.append(lh[-1])
-        ps.append(orc.crop_psnr(img.abs().cpu(), s["gt"].abs()))
-    print("final loss", finals, "oracle", ol[-1], "psnr", ps, "oracle", float(g["psnr"][-1]))
-    # The loss trajectory above is the parity evidence.  PSNR after 300 iterations is a chaotic
-    # observable: 40 runs of different builds gave 32.8..37.6 dB (mean 35.8, sigma 1.1) against the
-    # oracle's single 37.15 dB (one draw of the same distribution: the oracle's own run-to-run spread on
-    # the small golden cases is of the same size), so it is only guarded by a band.
-    assert 0.5 * ol[-1] <= float(np.median(finals)) <= 2.0 * ol[-1]
-    assert abs(float(np.median(ps)) - float(g["psnr"][-1])) <= 4.0
-    assert min(ps) >= 31.0
-
-
-def test_config2_3000_iterations_vs_cpu_oracle_record(env, golden):
-    """The metric's own configuration end to end: 320x320, 10 groups, 3000 iterations, slice 1, against the
-    recorded CPU-oracle run (tools/oracle_c2.py, 6.5 h on 4 cores -> tests/golden/c2_oracle_slice1_3000it.npz).
-    Loss checkpoints through the lambda_GE > 0 phase (median of 3 runs: single runs show the same rare spikes
-    as the oracle, e.g. 48.1 at iteration 1375 there, 56.7 at 1200 in one recorded HIP run), and the end state
-    after lambda has underflowed to 0 (iteration > 1500), where the oracle's PSNR falls from 36-42 dB to
-    34.5 dB and the HIP runs' to 28-34.5 dB (recorded: 31.08 / 34.40 / 33.62 / 33.44 and later 28.4 .. 32.7)."""
-    pkg, L, orc = env
-    from oracle import synth_cpu
-    from miccai24_immoco_amd.models.immoco import get_solver, lambda_schedule
+def _c2_slice1(pkg, golden):
+    """Slice 1 of config C2 exactly as the CPU-oracle records saw it (tests/golden/c2_slice1_input.npz)."""
+    from miccai24_immoco_amd import synth
     from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    g = golden("c2_slice1_input")
+    k = torch.from_numpy(g["kspace"]).cuda()
+    masks = pkg.extract_movement_groups(torch.from_numpy(g["lines"]).cuda(), make_list=True)
+    assert masks.shape[0] == int(g["n_groups"]) == 10
+    gt = synth.phantom(320, 320, 1000 + int(g["slice_idx"])).abs()
+    return k, k / k.abs().max() * 16000, masks, masks_to_col_group(masks), gt
+
+
+def _band(values, widen=0.5):
+    """[min - widen * spread, max + widen * spread] of a set of oracle draws."""
+    lo, hi = float(np.min(values)), float(np.max(values))
+    return lo - widen * (hi - lo), hi + widen * (hi - lo)
+
+
+def test_config2_distribution_vs_oracle_draws(env, golden):
+    """VERDICT r1 item 1b.  The first 401 iterations of the metric's 3000-iteration solve (slice 1), HIP against
+    SEVEN draws of the CPU oracle (tools/oracle_c2.py: six fp32 summation orders of the hash-grid backward plus
+    the head of the full record; tests/golden/c2_oracle_slice1_draws.npz).  The trajectory is chaotic - the
+    oracle's own draws differ by 25 % in the loss at iteration 400 - so parity is: identical start (the
+    draws agree to 1e-6 there), then the HIP MEDIAN inside the band the oracle draws span (widened by half their
+    spread, otherwise a same-distribution median would fall outside a 7-draw range about one time in ten)."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.immoco import get_solver, lambda_schedule
+    d = golden("c2_oracle_slice1_draws")
+    ol, op = d["loss"].astype(np.float64), d["psnr"].astype(np.float64)
+    assert ol.shape[0] >= 6 and ol.shape[1] == 401
+    k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
+    sol = get_solver(torch.device("cuda", 0), 320, 320, 10)
+    lam = lambda_schedule(3000, 1e-2)[:401]
+    losses, psnrs = [], []
+    for rep in range(5):
+        pi, pm = sol.init_params()
+        ai, am = torch.zeros(2 * pi.numel(), device="cuda"), torch.zeros(2 * pm.numel(), device="cuda")
+        img, _, loss = sol.solve(kin, cg, pi, pm, ai, am, 401, 1e-2, lam, want_loss=True)
+        losses.append(loss.cpu().numpy().astype(np.float64))
+        psnrs.append(orc.crop_psnr(img.abs().cpu(), gt))
+    hl = np.array(losses)
+    np.testing.assert_allclose(hl[:, :3], np.broadcast_to(ol[:, :3].mean(0), (5, 3)), rtol=5e-5)
+    np.testing.assert_allclose(hl[:, :6], np.broadcast_to(ol[:, :6].mean(0), (5, 6)), rtol=1e-3)   # oracle draws: 2.6e-4 apart at 5
+    # From a few dozen iterations on every trajectory carries its own +-3 % ripple from one iteration to the
+    # next (oracle draws at iteration 190 / 200 / 210: 28.3-30.0 / 28.0-28.6 / 28.2-29.7), so a checkpoint is the
+    # MEDIAN over a window of +-10 iterations: there the seven oracle draws agree to 1-3 %.
+    def win(x, j):
+        return np.median(x[:, max(j - 10, 0):j + 11], axis=1)
+    rep = {}
+    for j in (25, 50, 100, 200, 300, 390):
+        o, h = win(ol, j), win(hl, j)
+        lo, hi = _band(o)
+        lo, hi = min(lo, 0.985 * o.min()), max(hi, 1.015 * o.max())      # seven draws under-sample the tails
+        rep[j] = (round(float(np.median(h)), 3), round(float(o.min()), 3), round(float(o.max()), 3))
+        assert lo <= np.median(h) <= hi, (j, h, o)
+    plo, phi = _band(op[:, -1])
+    print("windowed loss: iteration -> (hip median of 5, oracle min, oracle max)", rep)
+    print("hip windowed per run @200", win(hl, 200).round(3).tolist(), "@390", win(hl, 390).round(3).tolist())
+    print("psnr @400: hip", [round(p, 2) for p in psnrs], "oracle draws", op[:, -1].round(2).tolist())
+    assert plo <= float(np.median(psnrs)) <= phi, (psnrs, op[:, -1])
+
+
+def test_config2_3000_iterations_vs_cpu_oracle_records(env, golden):
+    """The metric's own configuration end to end: 320x320, 10 groups, 3000 iterations, slice 1, against the
+    recorded full CPU-oracle runs (tests/golden/c2_oracle_slice1_3000it.npz) and, up to iteration 400, the band
+    of all oracle draws.  With the reference's schedule lambda_GE underflows to exactly 0 after iteration 1500
+    (SURVEY a15); from there only data consistency is minimised and PSNR falls by several dB in the oracle and in
+    HIP alike.  End state: loss converged by orders of magnitude; PSNR (a chaotic observable: the oracle records
+    themselves end several dB apart) inside the oracle records' range widened by 3 dB, and above the input's."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.immoco import get_solver, lambda_schedule
     g = golden("c2_oracle_slice1_3000it")
+    d = golden("c2_oracle_slice1_draws")
     ol = g["oracle_loss"].astype(np.float64)
-    assert ol.shape == (3000,)
-    s = synth_cpu.make_slice(320, 320, 10, int(g["slice_idx"]))
-    masks = pkg.extract_movement_groups(s["lines"].cuda(), make_list=True)
-    sol = get_solver(torch.device("cuda", 0), 320, 320, int(masks.shape[0]))
-    k = s["kspace"].cuda()
-    kin = k / k.abs().max() * 16000
-    cg = masks_to_col_group(masks)
+    assert ol.ndim == 2 and ol.shape[1] == 3000
+    dl = d["loss"].astype(np.float64)
+    k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
+    sol = get_solver(torch.device("cuda", 0), 320, 320, 10)
     lam = lambda_schedule(3000, 1e-2)
     assert lam == orc.lambda_schedule(3000, 1e-2) and lam[-1] == 0.0
-    marks = [0, 25, 50, 100, 200, 400, 800, 2999]
+    marks = [0, 25, 50, 100, 200, 400, 800, 1400, 2999]
     losses, psnrs = [], []
     for rep in range(3):
         pi, pm = sol.init_params()
@@ -1018,22 +1142,22 @@ def test_config2_3000_iterations_vs_cpu_oracle_record(env, golden):
             row.append(float(loss[-1]))
             a = end + 1
         losses.append(row)
-        psnrs.append(orc.crop_psnr(img.abs().cpu(), s["gt"].abs()))
+        psnrs.append(orc.crop_psnr(img.abs().cpu(), gt))
     med = np.median(np.array(losses), axis=0)
-    print("hip loss (median of 3)", dict(zip(marks, med.tolist())), "oracle", {m: float(ol[m]) for m in marks},
-          "psnr", psnrs, "oracle", float(g["oracle_psnr"][-1]))
-    for m, tol in ((0, 1e-4), (25, 0.02), (50, 0.08), (100, 0.08), (200, 0.06), (400, 0.15), (800, 0.15)):
+    p_in = orc.crop_psnr(pkg.IFFT(k).abs().cpu(), gt)
+    p_ref = g["oracle_psnr"][:, -1].astype(np.float64)
+    print("hip loss (median of 3)", dict(zip(marks, med.round(4).tolist())), "oracle records",
+          {m: ol[:, m].round(4).tolist() for m in marks}, "psnr hip", psnrs, "oracle", p_ref.tolist(), "input", p_in)
+    assert abs(med[0] - ol[0, 0]) <= 1e-4 * ol[0, 0]
+    for m in (25, 50, 100, 200, 400):
+        lo, hi = _band(dl[:, m])
+        assert lo <= med[marks.index(m)] <= hi, (m, med[marks.index(m)], dl[:, m])
+    for m in (800, 1400):      # only the full records reach this far: their range, widened by 15 %
         j = marks.index(m)
-        assert abs(med[j] - ol[m]) <= tol * ol[m], (m, med[j], ol[m])
-    # End state (lambda = 0 since iteration 1500): the loss has dropped from ~18 by more than an order of
-    # magnitude in both, but with lr = 1e-2 it keeps spiking (recorded last-iteration values 0.003 .. 0.97), and
-    # PSNR is a chaotic observable there: 10 HIP runs ended at 28.4 .. 34.4 dB, the oracle's single run at
-    # 34.5 dB after wandering between 32.5 and 35.4 dB over its last 1000 iterations; the corrupted input
-    # has 25.3 dB.  So: converged, better than the input, inside the band - not a dB-level comparison.
-    assert med[-1] <= 1.5 and ol[-1] <= 1.5
-    p_ref = float(g["oracle_psnr"][-1])
-    assert all(26.5 <= p <= 40.0 for p in psnrs), psnrs
-    assert abs(float(np.median(psnrs)) - p_ref) <= 7.0, (psnrs, p_ref)
+        assert 0.85 * ol[:, m].min() <= med[j] <= 1.15 * ol[:, m].max(), (m, med[j], ol[:, m])
+    assert med[-1] <= 1.5 and ol[:, -1].max() <= 1.5          # lambda = 0: converged by orders of magnitude
+    assert p_ref.min() - 3.0 <= float(np.median(psnrs)) <= p_ref.max() + 3.0, (psnrs, p_ref)
+    assert min(psnrs) >= p_in + 1.0, (psnrs, p_in)
 
 
 @pytest.mark.parametrize("tag", ["s32", "s64"])
@@ -1142,6 +1266,32 @@ def test_batch_solve_matches_single_slices(env):
         pkg.imcoco_motion_correction_batch(ksp, masks[:2], iters=30)
     with pytest.raises(L.ImmocoError):
         pkg.imcoco_motion_correction_batch(ksp.cpu(), masks, iters=30)
+
+
+def test_config3_batch_of_64_slices_at_320(env):
+    """BASELINE config 3 as stated: a batch of 64 independent 320x320 slices resident on one GPU (19.5 GB of
+    parameters + Adam state) through immoco_solver_solve_batch, 12 iterations, against per-slice calls; and two
+    slices in flight (lanes = 2) give the same numbers as slice after slice."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd import synth
+    B = 64
+    sls = [synth.make_slice(320, 320, 10, 100 + i, device="cuda") for i in range(B)]
+    masks = [pkg.extract_movement_groups(s["lines"], make_list=True) for s in sls]
+    ksp = torch.stack([s["kspace"] for s in sls])
+    imgs, kfms, loss = pkg.imcoco_motion_correction_batch(ksp, masks, iters=12, return_loss=True)
+    assert imgs.shape == (B, 320, 320) and loss.shape == (B, 12)
+    assert bool(torch.isfinite(loss).all()) and bool((loss[:, -1] < loss[:, 0]).all())
+    assert len({round(float(v), 1) for v in loss[:, 0]}) > B // 2            # different problems
+    for i in (0, 31, 63):
+        im1, _, l1 = pkg.imcoco_motion_correction(ksp[i], masks[i], iters=12, return_loss=True)
+        np.testing.assert_allclose(loss[i, :3].cpu().numpy(), l1[:3].cpu().numpy(), rtol=2e-5)
+        np.testing.assert_allclose(loss[i, :6].cpu().numpy(), l1[:6].cpu().numpy(), rtol=1e-2)   # two HIP runs: 3e-3 at it 5
+        np.testing.assert_allclose(loss[i].cpu().numpy(), l1.cpu().numpy(), rtol=5e-2)
+        assert float((imgs[i] - im1).abs().norm() / im1.abs().norm()) < 0.05
+    sub = [0, 1, 2, 3, 4]
+    _, _, l2 = pkg.imcoco_motion_correction_batch(ksp[sub], [masks[i] for i in sub], iters=12, return_loss=True, lanes=2)
+    np.testing.assert_allclose(l2[:, :3].cpu().numpy(), loss[sub, :3].cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(l2.cpu().numpy(), loss[sub].cpu().numpy(), rtol=5e-2)
 
 
 def test_probe_and_batch_argument_checks(env):

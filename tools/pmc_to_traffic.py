@@ -2,16 +2,17 @@
 """Turn the two rocprofv3 PMC passes of tools/final_profile.sh (--pmc FETCH_SIZE, --pmc WRITE_SIZE, separate
 runs, `python bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline`) into
   profiles/<tag>_pmc_fetch_write_kb_per_launch.csv   per-kernel launch averages, and
-  profiles/r01_traffic.json                          HBM bytes per launch for bench.py's `roofline.traffic`,
+  profiles/<round>_traffic.json                      HBM bytes per launch for bench.py's `roofline.traffic`,
 with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md: (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 
-    python tools/pmc_to_traffic.py gpurun_out/final r01_final
+    python tools/pmc_to_traffic.py gpurun_out/final r02_final
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
+traffic_name = tag.split("_")[0] + "_traffic.json"      # r02_final -> profiles/r02_traffic.json (read by bench.py)
 PHASE = [("hashgrid_fwd_kernel<2", "image_encode_fwd"), ("hashgrid_fwd_kernel<3", "motion_encode_fwd"),
          ("mlp_fwd_mfma_kernel<256", "image_mlp_fwd"), ("mlp_fwd_mfma_kernel<64", "motion_mlp_fwd"),
          ("motion_warp_fwd_kernel", "motion_warp_fwd"), ("motion_warp_bwd", "motion_warp_bwd"),
@@ -28,7 +29,7 @@ for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             if row["Counter_Name"] != counter:
                 continue
             name = row["Kernel_Name"]
-            if "adam_kernel" in name:       # image and motion share the kernel: tell them apart by grid size
+            if "adam_" in name:             # image and motion share the kernel: tell them apart by grid size
                 name += f" [grid {row['Grid_Size']}]"
             a = acc[name]
             a[0] += 1
@@ -43,7 +44,7 @@ with open(out_csv, "w", newline="") as f:
     for c, k, n, v in rows:
         w.writerow([c, k[:110], n, round(v, 1)])
 kern = {}
-adam = sorted((k for k in agg["FETCH_SIZE"] if "adam_kernel" in k),
+adam = sorted((k for k in agg["FETCH_SIZE"] if "adam_" in k),
               key=lambda k: -agg["FETCH_SIZE"][k][1])
 names = dict(PHASE)
 for k in set(agg["FETCH_SIZE"]) | set(agg["WRITE_SIZE"]):
@@ -60,5 +61,5 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
                      "--steps 1 --warmup 0 --no-cpu-baseline; per-launch averages; hbm_bytes_corrected = "
                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads, "
                      "MI355X_MICROARCH.md; uncalibrated for 8-byte gathers); tools/pmc_to_traffic.py",
-           "kernels": dict(sorted(kern.items()))}, open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
-print("wrote", out_csv, "and profiles/r01_traffic.json:", {k: v["hbm_bytes_corrected"] for k, v in kern.items()})
+           "kernels": dict(sorted(kern.items()))}, open(os.path.join(ROOT, "profiles", traffic_name), "w"), indent=1)
+print("wrote", out_csv, "and profiles/" + traffic_name + ":", {k: v["hbm_bytes_corrected"] for k, v in kern.items()})
