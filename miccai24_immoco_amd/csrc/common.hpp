@@ -104,6 +104,23 @@ __host__ __device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
   return (word >> 22u) ^ word;
 }
 
+// n / d for index arithmetic.  hipcc expands a 64-bit (and even a 32-bit) integer division into a long
+// multiply/correct sequence - ~100 VALU instructions per `(i / W) % H` on an int64 index, which made the
+// per-thread index decomposition the largest VALU cost of the gather and pointwise kernels (round 2: the
+// encode forward issued ~350 VALU instructions per (point, level), most of them three 64-bit divisions).
+// For n < 2^24 the quotient comes from ONE correctly rounded float reciprocal: float(n) is exact, the product's
+// relative error is below 2^-23, so the truncated quotient is off by at most one for d >= 2 and one correction
+// step each way makes it exact (d = 1 is handled by the caller's layouts: a stride of 1 is never divided by).
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t d) {
+  if (n < (1u << 24) && d < (1u << 24)) {
+    uint32_t q = (uint32_t)((float)n * (1.0f / (float)d));
+    q -= (q * d > n) ? 1u : 0u;
+    q += ((q + 1u) * d <= n) ? 1u : 0u;
+    return q;
+  }
+  return n / d;
+}
+
 // wave64 sum via DPP-free shuffles (width 64).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -140,9 +140,12 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(Levels lv, AxisPtrs
       // weight = -(product of the other dimensions' factors); the dim-0 fraction comes from a per-level
       // table at run time.  One dL/denc gather then serves two slots.
       // (Round 2 tried the general rule - any dim-0 pair inside one slot block, partner at slot ^ (c0 ^ (c0+1))
-      // on hashed levels: 35 % fewer entries and gathers, 59 M instead of 90 M, but the partner sums need
-      // scattered LDS float atomics, which cost 3 clocks PER LANE on this chip (tools/bench_lds_atomic.hip):
-      // 0.58 / 0.48 ms instead of 0.43.)
+      // on hashed levels: 21-35 % fewer entries and gathers (71 M / 59 M instead of 90 M).  With the SAME kernel
+      // the time follows the entry count (0.335 ms for 69 M entries in a timing-only experiment), but the far
+      // partner's share has to go somewhere: scattered LDS float atomics cost 3 clocks PER LANE on this chip
+      // (tools/bench_lds_atomic.hip): 0.58 / 0.48 / 0.43 ms; per-class partner sums carried with the run and
+      // stored into extra LDS tiles (no atomics) need 160 VGPRs and 43 KB of LDS: 3 waves/SIMD, 0.447 ms, and
+      // 4.3 instead of 3.5 ms at 640x640x20.  Neither beats the aligned-pair rule's 0.449 ms.)
       const uint32_t even = idx[pair][0] & ~1u, swap = idx[pair][0] & 1u;
       const uint32_t key = kbase + even;
       const uint32_t pos = atomicAdd(counts_or_cursor + key, 1u);

@@ -62,19 +62,41 @@ int build_levels(const immoco_grid_cfg* cfg, Levels* out) {
 }
 
 // ---------------------------------------------------------------------------
+// Lattice layouts (checked by the launchers): D = 3: (m, row, col), strides (n1*n2, n2, 1); D = 2: dim 0 = column
+// (stride 1), dim 1 = row (stride n0).  The point index is decomposed with fast_div (no 64-bit divisions).
 template <int D, bool LAT>
 __device__ __forceinline__ void load_coords(const float* __restrict__ coords, const Lattice& lat,
                                             int64_t p, float (&x)[D]) {
   if (LAT) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      int32_t i = (int32_t)((p / lat.stride[d]) % lat.n[d]);
-      x[d] = lat.axis[d][i];
+    const uint32_t q = (uint32_t)p;
+    if (D == 3) {
+      const uint32_t i0 = fast_div(q, (uint32_t)lat.stride[0]);
+      const uint32_t rem = q - i0 * (uint32_t)lat.stride[0];
+      const uint32_t i1 = fast_div(rem, (uint32_t)lat.stride[1]);
+      x[0] = lat.axis[0][i0];
+      x[1] = lat.axis[1][i1];
+      if (D > 2) x[2] = lat.axis[2][rem - i1 * (uint32_t)lat.stride[1]];
+    } else {
+      const uint32_t i1 = fast_div(q, (uint32_t)lat.stride[1]);
+      x[0] = lat.axis[0][q - i1 * (uint32_t)lat.stride[1]];
+      x[1] = lat.axis[1][i1];
     }
   } else {
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = coords[p * D + d];
   }
+}
+
+static int check_lattice(const Levels& lv, const Lattice& lat, int64_t n) {
+  IMMOCO_REQUIRE(n < (1ll << 32), "lattice of %lld points: too large for 32-bit point indices", (long long)n);
+  if (lv.dims == 3)
+    IMMOCO_REQUIRE(lat.stride[2] == 1 && lat.stride[1] == lat.n[2] && lat.stride[0] == lat.n[1] * lat.n[2] &&
+                       (int64_t)lat.n[0] * lat.n[1] * lat.n[2] == n,
+                   "3-D lattice must be (m, row, col) row-major");
+  else
+    IMMOCO_REQUIRE(lat.stride[0] == 1 && lat.stride[1] == lat.n[0] && (int64_t)lat.n[0] * lat.n[1] == n,
+                   "2-D lattice must be (x = col, y = row) row-major");
+  return IMMOCO_OK;
 }
 
 // A/B switch (environment, read once): IMMOCO_ENC_STORE=plain keeps the streamed encoding in L2
@@ -237,7 +259,11 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "encoding strides must be even (float2 stores)");
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   Lattice L{};
-  if (lat) L = *lat;
+  if (lat) {
+    L = *lat;
+    int rc = check_lattice(lv, L, n);
+    if (rc) return rc;
+  }
   const float2* t = reinterpret_cast<const float2*>(table);
   if (lv.dims == 2) {
     if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
@@ -254,6 +280,10 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
                              int64_t ps, int64_t ls, hipStream_t st) {
   if (n == 0) return IMMOCO_OK;
+  {
+    int rc = check_lattice(lv, lat, n);
+    if (rc) return rc;
+  }
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   const __half2* t = reinterpret_cast<const __half2*>(table_half2);
   if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());

@@ -26,7 +26,8 @@ struct Step {
   const char* name;
   std::function<int(hipStream_t)> run;
   int branch = 0;
-  int group = 2;  // 0 image forward, 1 motion forward, 2 serial middle, 3 motion backward, 4 image backward, 5 tick
+  int group = 2;  // 0 image forward, 1 motion forward, 2 serial middle (.. motion MLP backward), 3 motion encode
+                  // backward, 4 image backward (MLP, encode, Adam), 5 tick, 6 motion Adam
 };
 
 }  // namespace immoco
@@ -95,7 +96,7 @@ struct Bind {
 };
 
 // The per-iteration kernel sequence (immoco.py:166-175).
-std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward, int img_adam_off = 0) {
+std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   const immoco_solver_cfg& c = s->cfg;
   const int H = c.H, W = c.W, nM = c.nM;
   const int64_t P = s->P, NP = s->NP;
@@ -206,7 +207,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward, in
                     const uint2* blocks = csr_plan_touched(s->plan_img, &nb);
                     return launch_adam_blocks(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
                                               s->n_w_img, blocks, nb, s->sched, s->iter_dev, 0.9f, 0.999f, 1e-8f, q,
-                                              s->cfg.table_fp16 ? s->shadow_img : nullptr, img_adam_off);
+                                              s->cfg.table_fp16 ? s->shadow_img : nullptr);
                   }
                   return launch_adam_sched(b.p_img, s->grad_img, 1, 0, b.a_img, b.a_img + s->n_params_img,
                                            s->n_params_img, s->n_params_img, s->sched, s->iter_dev, 0.9f, 0.999f,
@@ -221,29 +222,39 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward, in
     const std::string n = x.name;
     x.group = (n == "image_encode_fwd" || n == "image_mlp_fwd" || n == "image_to_fft_slot") ? 0
               : (n == "motion_encode_fwd" || n == "motion_mlp_fwd")                             ? 1
-              : (n == "motion_encode_bwd" || n == "adam_motion")                                ? 3
+              : n == "motion_encode_bwd"                                                        ? 3
               : (n == "image_mlp_bwd" || n == "image_encode_bwd" || n == "adam_image")         ? 4
               : n == "tick"                                                                     ? 5
+              : n == "adam_motion"                                                              ? 6
                                                                                                 : 2;
   }
   return st;
 }
 
-// Software pipelining ACROSS iterations (round 2).  In the classic order [image fwd || motion fwd] -> middle ->
-// [motion bwd || image bwd] the image chain's backward is the tail of the iteration: its MFMA kernel needs a
-// whole SIMD's registers and starves beside the motion grid's encode backward (0.62 ms instead of 0.14), so the
-// iteration ends ~0.08 ms after the motion chain has finished.  Nothing of iteration k+1's MOTION forward depends
-// on the image parameters, so the image backward of iteration k (MLP backward, encode backward, Adam) is deferred
-// to the start of iteration k+1, in front of that iteration's image forward and beside its motion encode forward:
-//   first:   [image fwd(0) || motion fwd(0)] -> middle(0) -> motion bwd(0) -> tick
-//   steady:  [image bwd(k-1), image fwd(k) || motion fwd(k)] -> middle(k) -> motion bwd(k) -> tick
-//   last:    image bwd(n-1)
-// Every parameter sees the same updates in the same order as before (the deferred Adam reads the schedule of its
-// own iteration: iter_off = -1); only the launch order changes.
-// MEASURED (MI355X, 320x320x10): 1.446 ms per iteration instead of 1.351 - the deferred MFMA kernel starves beside
-// the motion encode FORWARD just as it did beside the backward (that gather holds all 8 wave slots of every SIMD),
-// and now it sits in front of the image forward that the warp waits for.  Kept behind IMMOCO_PIPELINE=1 as an A/B
-// switch; the default is the classic order.
+// Software pipelining ACROSS iterations (round 2).  In the classic order
+//     [image fwd || motion fwd] -> middle -> [motion encode bwd, motion Adam || image bwd] -> tick
+// the image chain's backward runs BESIDE the motion grid's encode backward, the dominant kernel: its MFMA kernel
+// needs a whole SIMD's registers and starves there (0.62 ms instead of 0.14), the gather it runs beside slows
+// from 0.45 to 0.58 ms, and the iteration still ends with the image chain ~0.08 ms after the motion chain.
+// Nothing of iteration k+1's MOTION forward depends on the image parameters, and the image backward needs
+// nothing of the motion grid's backward, so the iteration is ROTATED: the replayed graph runs from the end of
+// one motion encode backward to the end of the next,
+//   first:    [image fwd(0) || motion fwd(0)] -> middle(0) -> motion encode bwd(0)
+//   steady:   [motion Adam(k), motion fwd(k+1) || image bwd(k), image fwd(k+1)] -> tick -> middle(k+1)
+//                                                                             -> motion encode bwd(k+1)
+//   last:     [motion Adam(n-1) || image bwd(n-1)]
+// so that the dominant gather runs ALONE and the image chain's 0.3 ms (backward + next forward) sit beside
+// the motion Adam (HBM-bound, short workgroups) and the motion encode forward.  Both Adam kernels read the
+// schedule of their own iteration because the tick comes after the join.  Every parameter sees the same
+// updates in the same order as before; only the launch order changes.
+// MEASURED (MI355X, 320x320x10, rocprofv3 kernel trace): the dominant gather does run alone (0.44 ms instead of
+// 0.58), but the motion encode FORWARD beside the image chain takes 0.51 ms instead of 0.27 and the image encode
+// backward 0.19 instead of 0.04: a level slice of the fp32 table is exactly one XCD L2 (4 MB), and any stream of
+// other lines through that L2 pushes the forward over the cliff immoco_probe_gather shows between 4 and 8 MB
+// footprints (259 -> 120 G requests/s).  1.44 ms per iteration against 1.35 in the classic order, which
+// therefore stays the default; IMMOCO_PIPELINE=1 selects this order (A/B switch).
+// (A first variant that merely deferred the image backward to the FRONT of the next iteration, ahead of the
+// image forward the warp waits for, was slower: 1.446 vs 1.351 ms.)
 enum class Order { Classic, First, Steady, Epilogue };
 
 std::vector<Step> arrange(const std::vector<Step>& all, Order o) {
@@ -258,15 +269,22 @@ std::vector<Step> arrange(const std::vector<Step>& all, Order o) {
       }
   };
   if (o == Order::Epilogue) {
-    take(4, 0);
+    take(6, 1);
+    take(4, 2);
     return out;
   }
-  if (o == Order::Steady) take(4, 2);
-  take(0, 2);
-  take(1, 1);
+  if (o == Order::Steady) {
+    take(6, 1);
+    take(1, 1);
+    take(4, 2);
+    take(0, 2);
+    take(5, 0);
+  } else {
+    take(0, 2);
+    take(1, 1);
+  }
   take(2, 0);
   take(3, 0);
-  take(5, 0);
   return out;
 }
 
@@ -585,11 +603,10 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
   if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
   Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
-  // pipelined order (image backward of iteration k beside the motion forward of iteration k+1, see arrange()):
-  // an A/B switch, OFF by default - measured 1.446 instead of 1.351 ms per iteration at 320x320x10
+  // rotated order (see arrange()): an A/B switch (IMMOCO_PIPELINE=1), OFF by default - measured slower
   static const bool want_pipeline = getenv("IMMOCO_PIPELINE") != nullptr;
-  const bool pipelined = want_pipeline && s->cfg.nM > 0 && !s->cfg.serial_chains && s->plan_img && s->plan_mot;
-  const std::vector<Step> all = build_steps(s, b, true, pipelined ? -1 : 0);
+  const bool pipelined = want_pipeline && s->cfg.nM > 0 && !s->cfg.serial_chains;
+  const std::vector<Step> all = build_steps(s, b, true);
   const std::vector<Step> first = arrange(all, pipelined ? Order::First : Order::Classic);
   const std::vector<Step> steady = pipelined ? arrange(all, Order::Steady) : first;
   auto run_list = [&](const std::vector<Step>& l) { return s->cfg.serial_chains ? run_steps(l, q) : run_steps_forked(s, l, q); };
@@ -624,7 +641,7 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
       return rc;
     }
   }
-  if (pipelined && (rc = run_steps(arrange(all, Order::Epilogue), q))) return rc;   // image backward of the last iteration
+  if (pipelined && (rc = run_steps_forked(s, arrange(all, Order::Epilogue), q))) return rc;   // Adam steps of the last iteration
   // tensors of the LAST forward pass (immoco.py:203-206)
   if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
   if (out_kspace && (rc = launch_transpose_c64(s->kout, out_kspace, s->cfg.W, s->cfg.H, q))) return rc;
