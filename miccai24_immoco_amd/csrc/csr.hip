@@ -228,6 +228,12 @@ constexpr int EPT = 16;                  // entries per thread per chunk
 //     neighbour is another wave) - uses float atomics, into a SECOND tile, so that they never race with
 //     the plain stores; the result is the sum of the two tiles.
 // Exactly one lane holds a run's first entry, so every slot gets at most one plain store.
+// Ablation (round 2, 320x320x10): with the divergent dL/denc gathers replaced by one shared line the kernel
+// still takes 0.23 of its 0.455 ms - the 724 MB entry stream (3.2 TB/s) plus ~40 VALU instructions per entry -
+// and the gathers ADD their 0.22 ms instead of hiding under it: 61.6 M L1->L2 requests per launch (rocprofv3
+// TCP_TCC_READ_REQ) at 137 G/s, half of what immoco_probe_gather sustains with nothing else in flight.  (Issuing
+// the gathers ahead of the next chunk's prefetch - vector-memory results return in issue order - is undone by
+// the compiler, which sinks the last two gathers below the prefetch loads again; no change in the time.)
 template <int DIMS, bool PAIR>  // DIMS names the instantiation (2: image grid, 3: motion grid) in profiles
 __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
