@@ -198,8 +198,8 @@ def main():
         dt = float(t.item())
     value = K * B * world / dt
     ms_per_step = dt / K * 1e3
-    graph_used = bool(get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0,
-                                 args.table_fp16).graph_active)          # of the timed solves
+    graph_used = bool(get_solver(dev, H, W, nM, not args.no_graph, False, 0 if B > 1 else args.grad_parts, 0,
+                                 args.table_fp16, args.lanes if B > 1 else 0).graph_active)   # of the timed solves
 
     out = None
     if rank == 0:
@@ -252,7 +252,8 @@ def main():
         ms = dict(phases)[name]
         ms_conc = dom_ms if dom_ms > 0 else ms
         achieved = ab[name] / (ms * 1e-3) / 1e9
-        b_iter = 28 * (solver.n_params_image + solver.n_params_motion) + 8 * H * W
+        # 28 B per parameter (30 with the fp16 shadow write of config 5) + 8 B per pixel
+        b_iter = (30 if args.table_fp16 else 28) * (solver.n_params_image + solver.n_params_motion) + 8 * H * W
         iter_ms_graph = ms_per_step / args.iters / B
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if args.workload != "c5" else "r02_traffic_c5.json")
