@@ -217,8 +217,9 @@ def main():
             psnr_delta = {"psnr_delta_db": round(sum(hip) / len(hip) - om, 3), "slice": "config C2, slice 1",
                           "hip_psnr_db": [round(p, 3) for p in hip], "hip_timed_run_psnr_db": round(psnr[0], 3),
                           "oracle_psnr_db": ref_rec["oracle_psnr_db"], "oracle_source": ref_rec["source"],
-                          "note": "mean over runs minus mean over oracle records; single runs of either side spread "
-                                  "by several dB after lambda_GE has underflowed to 0 at iteration 1500 (DESIGN.md 2)"}
+                          "note": "mean over HIP runs minus mean over oracle records; single HIP runs spread by +-2 dB "
+                                  "(the oracle's records by 0.8 dB) once lambda_GE has underflowed to 0 at iteration "
+                                  "1500 (DESIGN.md 2)"}
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
         solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16)
         sl = slices[0]

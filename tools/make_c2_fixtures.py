@@ -23,14 +23,17 @@ for d in draws + full:
     assert int(d["slice_idx"]) == 1 and np.array_equal(d["kspace"], ref["kspace"]) and np.array_equal(d["lines"], ref["lines"])
 np.savez_compressed(os.path.join(OUT, "c2_slice1_input.npz"), kspace=ref["kspace"].astype(np.complex64),
                     lines=ref["lines"], slice_idx=np.int32(1), n_groups=np.int32(ref["n_groups"]))
-# the first 401 iterations of every full record are draws too
-loss = [d["loss"][:401] for d in draws] + [d["loss"][:401] for d in full]
-psnr = [d["psnr"][:17] for d in draws] + [d["psnr"][:17] for d in full]
+# the first 401 iterations of every full record are draws too (unless a draw with the same summation order and
+# thread count exists: the oracle is deterministic, that would be the same trajectory twice)
+seen = {(int(d["order"]), int(d["threads"])) for d in draws}
+heads = [d for d in full if (int(d["order"]), int(d["threads"])) not in seen]
+loss = [d["loss"][:401] for d in draws] + [d["loss"][:401] for d in heads]
+psnr = [d["psnr"][:17] for d in draws] + [d["psnr"][:17] for d in heads]
 assert all(np.array_equal(d["psnr_iters"][:17], np.arange(0, 401, 25)) for d in draws + full)
 np.savez_compressed(os.path.join(OUT, "c2_oracle_slice1_draws.npz"), loss=np.array(loss, dtype=np.float32),
                     psnr_iters=np.arange(0, 401, 25, dtype=np.int32), psnr=np.array(psnr, dtype=np.float32),
-                    order=np.array([int(d["order"]) for d in draws + full], dtype=np.int32),
-                    threads=np.array([int(d["threads"]) for d in draws + full], dtype=np.int32), slice_idx=np.int32(1))
+                    order=np.array([int(d["order"]) for d in draws + heads], dtype=np.int32),
+                    threads=np.array([int(d["threads"]) for d in draws + heads], dtype=np.int32), slice_idx=np.int32(1))
 np.savez_compressed(os.path.join(OUT, "c2_oracle_slice1_3000it.npz"),
                     oracle_loss=np.array([d["loss"] for d in full], dtype=np.float32),
                     oracle_psnr_iters=full[0]["psnr_iters"].astype(np.int32),
