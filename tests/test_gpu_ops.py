@@ -562,12 +562,15 @@ def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K):
         rep[name] = dict(grad_rel_l2=rel_l2, grad_max_abs_over_max=max_abs, upd_rel_l2=float(d.norm() / upd_o.norm()),
                          upd_max=float(d.max()), frac_update_off_by_1e3_lr=frac_off, n_moved=int(moved.sum()),
                          n_untouched=int(untouched.sum()), untouched_moved_by_hip=int((upd_h[untouched] != 0).sum()),
-                         max_oracle_step_where_hip_is_still=float(upd_o[upd_h == 0].abs().max()),
+                         # beyond a rounding-sized step (2 ulp of the parameter) or 1e-5 * lr in absolute terms: a
+                         # block wrongly skipped by the touched-blocks Adam would show steps of ~lr here
+                         max_oracle_step_where_hip_is_still=float(
+                             (upd_o[upd_h == 0].abs() - (p0[upd_h == 0].abs() * 2.0 ** -22 + 1e-7)).max()),
                          n_pattern_mismatch=int(((upd_h == 0) != (upd_o == 0)).sum()))
     print("teacher-forced", rep)
     for name in ("img", "mot"):
         assert rep[name]["untouched_moved_by_hip"] == 0, (name, rep[name])
-        assert rep[name]["max_oracle_step_where_hip_is_still"] <= 1e-7, (name, rep[name])   # <= 1 ulp of a weight
+        assert rep[name]["max_oracle_step_where_hip_is_still"] <= 0.0, (name, rep[name])   # nothing beyond rounding
     return rep
 
 
@@ -590,6 +593,28 @@ def test_teacher_forced_late_state_96(env, K):
         assert r["grad_rel_l2"] <= 1e-4 and r["grad_max_abs_over_max"] <= 1e-4, (name, r)
         assert r["upd_max"] <= 1e-3 * 1e-2 and r["frac_update_off_by_1e3_lr"] == 0.0, (name, r)
         assert r["upd_rel_l2"] <= 1e-3, (name, r)
+
+
+def test_teacher_forced_lambda_zero_phase_96(env):
+    """The same where lambda_GE has underflowed: 400-iteration schedule, K = 360 - 157 halvings (immoco.py:180-181,
+    SURVEY a15), 1e-2 * 2^-157 is exactly 0 in fp32 on both sides, so only data consistency is minimised, the
+    state in which every full-size solve spends its second half.  (Diagnostic at K = 1600 of the 3000-iteration
+    schedule, 4 minutes of CPU: this small case has run away by then in the oracle and in HIP alike - loss 2.2e5,
+    saturated tanh - and one step still agrees: loss 217434.52 vs 217434.50, gradient rel. L2 5e-5 / 1.4e-3,
+    largest update difference 1.3e-4 * lr.)"""
+    pkg, L, orc = env
+    from oracle import synth_cpu
+    s = synth_cpu.make_slice(96, 96, 3, 11)
+    masks = orc.extract_movement_groups(s["lines"], make_list=True)
+    rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 400, 360)
+    assert np.float32(rep["lambda"]) == 0.0
+    # measured: loss 0.0073231 vs 0.0073230 (the loss is a 1e-10 residual of k-space values up to 16000 there),
+    # gradient rel. L2 1.5e-4 / 1.4e-4, largest update difference 3.3e-7 = 3e-5 * lr
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) <= 1e-4 * rep["loss_oracle"]
+    for name in ("img", "mot"):
+        r = rep[name]
+        assert r["grad_rel_l2"] <= 1e-3 and r["grad_max_abs_over_max"] <= 1e-3, (name, r)
+        assert r["upd_max"] <= 1e-3 * 1e-2 and r["frac_update_off_by_1e3_lr"] == 0.0 and r["upd_rel_l2"] <= 5e-3, (name, r)
 
 
 def test_teacher_forced_state_c2_shape(env):
