@@ -112,6 +112,20 @@ static int enc_store_sc1() {
 // BASELINE config 5 / what tiny-cuda-nn itself gathers); interpolation is accumulated in fp32 either way.
 __device__ __forceinline__ float2 tab_to_f2(float2 v) { return v; }
 __device__ __forceinline__ float2 tab_to_f2(__half2 v) { return __half22float2(v); }
+// one load of an aligned slot pair (16 bytes of an fp32 table, 8 of an fp16 one)
+__device__ __forceinline__ void load_pair(const float2* __restrict__ p, float2& lo, float2& hi) {
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  lo = make_float2(q.x, q.y);
+  hi = make_float2(q.z, q.w);
+}
+__device__ __forceinline__ void load_pair(const __half2* __restrict__ p, float2& lo, float2& hi) {
+  const uint2 q = *reinterpret_cast<const uint2*>(p);
+  union { uint32_t u; __half2 h; } a, b;
+  a.u = q.x;
+  b.u = q.y;
+  lo = __half22float2(a.h);
+  hi = __half22float2(b.h);
+}
 
 // One (point, level) of the encoding: gathers the 2^D corners and interpolates.
 // The two corners that differ in dimension 0 sit in ONE aligned 16-byte pair of the table whenever
@@ -132,35 +146,48 @@ __device__ __forceinline__ float2 encode_point_level(const Levels& lv, int l, co
   float fr[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) pos_fract(x[d], scale, cell[d], fr[d]);
-  float2 v[1 << D];
-  float wgt[1 << D];
+  constexpr int NCORN = 1 << D;
+  uint32_t idx[NCORN];
+  float wgt[NCORN];
 #pragma unroll
-  for (int pair = 0; pair < (1 << (D - 1)); ++pair) {
-    uint32_t idx[2];
+  for (int corner = 0; corner < NCORN; ++corner) {
+    uint32_t c[D];
+    float w = 1.0f;
 #pragma unroll
-    for (int b0 = 0; b0 < 2; ++b0) {
-      const int corner = 2 * pair + b0;
-      uint32_t c[D];
-      float w = 1.0f;
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const bool hi = (corner >> d) & 1;
-        c[d] = cell[d] + (hi ? 1u : 0u);
-        w = mul_nc(w, hi ? fr[d] : sub_nc(1.0f, fr[d]));
-      }
-      idx[b0] = grid_index<D>(c, size, res, hashed, pow2);
-      wgt[corner] = w;
+    for (int d = 0; d < D; ++d) {
+      const bool hi = (corner >> d) & 1;
+      c[d] = cell[d] + (hi ? 1u : 0u);
+      w = mul_nc(w, hi ? fr[d] : sub_nc(1.0f, fr[d]));
     }
-    if (D == 3 && (idx[0] ^ idx[1]) == 1u) {
-      struct alignas(2 * sizeof(TAB)) Pair { TAB lo, hi; };
-      const Pair q = *reinterpret_cast<const Pair*>(tab + (idx[0] & ~1u));
-      const float2 lo = tab_to_f2(q.lo), hi = tab_to_f2(q.hi);
-      v[2 * pair] = (idx[0] & 1u) ? hi : lo;
-      v[2 * pair + 1] = (idx[0] & 1u) ? lo : hi;
-    } else {
-      v[2 * pair] = tab_to_f2(tab[idx[0]]);
-      v[2 * pair + 1] = tab_to_f2(tab[idx[1]]);
+    idx[corner] = grid_index<D>(c, size, res, hashed, pow2);
+    wgt[corner] = w;
+  }
+  // ALL gathers of the point are issued back to back, in straight-line code, before the first one is consumed.
+  // (Round 1 decided "merged pair or two loads" per pair inside a per-lane branch: the compiler then has to
+  // drain the loads (s_waitcnt vmcnt(0)) inside each branch, so a lane never had more than two gathers in
+  // flight - found in the ISA in round 2.)  Whether the two dim-0 corners of EVERY pair form an aligned slot pair
+  // is decided once per wave (a scalar branch): for the motion lattice dim 0 is the motion group, constant over
+  // a wave.
+  float2 v[NCORN];
+  bool merge = D == 3;
+#pragma unroll
+  for (int pair = 0; pair < NCORN / 2; ++pair) merge = merge && ((idx[2 * pair] ^ idx[2 * pair + 1]) == 1u);
+  if (D == 3 && __all(merge)) {
+    float2 lo[NCORN / 2], hi[NCORN / 2];
+#pragma unroll
+    for (int pair = 0; pair < NCORN / 2; ++pair) load_pair(tab + (idx[2 * pair] & ~1u), lo[pair], hi[pair]);
+#pragma unroll
+    for (int pair = 0; pair < NCORN / 2; ++pair) {
+      const bool odd = idx[2 * pair] & 1u;
+      v[2 * pair] = odd ? hi[pair] : lo[pair];
+      v[2 * pair + 1] = odd ? lo[pair] : hi[pair];
     }
+  } else {
+    TAB t[NCORN];
+#pragma unroll
+    for (int corner = 0; corner < NCORN; ++corner) t[corner] = tab[idx[corner]];
+#pragma unroll
+    for (int corner = 0; corner < NCORN; ++corner) v[corner] = tab_to_f2(t[corner]);
   }
   float a0 = 0.f, a1 = 0.f;
 #pragma unroll
