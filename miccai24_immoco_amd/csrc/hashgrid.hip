@@ -231,6 +231,124 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
   }
 }
 
+// Large 3-D lattices: K points per thread, three phases - indices and weights of all K points, then ALL their
+// gathers back to back, then the interpolation.  Ablations of the one-point kernel at 320x320x10 (0.261 ms): index
+// arithmetic alone 0.070 ms, no store 0.239, every level gathering from ONE 4 MB slice (no compulsory misses)
+// 0.242, both 0.216 - the pieces add up instead of overlapping, because a wave lives for one (point, level):
+// compute, load, wait, combine, exit.  Same arithmetic per point: bit-identical.
+template <typename TAB, int K>
+__global__ __launch_bounds__(256) void hashgrid_fwd_lat3_kernel(Levels lv, Lattice lat, int64_t n,
+                                                                const TAB* __restrict__ table,
+                                                                float* __restrict__ enc, int64_t ps, int64_t ls,
+                                                                int store_sc1) {
+  constexpr int NCORN = 8;
+  const int l = blockIdx.y;
+  const float scale = lv.scale[l];
+  const uint32_t size = lv.size[l], res = lv.res[l];
+  const bool hashed = (lv.hashed >> l) & 1u, pow2 = (lv.pow2 >> l) & 1u;
+  const TAB* __restrict__ tab = table + lv.offset[l];
+  int64_t p[K];
+  uint32_t idx[K][NCORN];
+  float wgt[K][NCORN];
+  bool merge = true;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    p[k] = ((int64_t)blockIdx.x * K + k) * 256 + threadIdx.x;
+    const int64_t pc = p[k] < n ? p[k] : n - 1;   // tail lanes recompute the last point (never stored)
+    float x[3];
+    load_coords<3, true>(nullptr, lat, pc, x);
+    uint32_t cell[3];
+    float fr[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos_fract(x[d], scale, cell[d], fr[d]);
+#pragma unroll
+    for (int corner = 0; corner < NCORN; ++corner) {
+      uint32_t c[3];
+      float w = 1.0f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const bool hi = (corner >> d) & 1;
+        c[d] = cell[d] + (hi ? 1u : 0u);
+        w = mul_nc(w, hi ? fr[d] : sub_nc(1.0f, fr[d]));
+      }
+      idx[k][corner] = grid_index<3>(c, size, res, hashed, pow2);
+      wgt[k][corner] = w;
+    }
+#pragma unroll
+    for (int pair = 0; pair < NCORN / 2; ++pair) merge = merge && ((idx[k][2 * pair] ^ idx[k][2 * pair + 1]) == 1u);
+  }
+  float2 v[K][NCORN];
+  if (__all(merge)) {   // every dim-0 corner pair of every point of the wave is an aligned slot pair: 16-byte loads
+    float2 lo[K][NCORN / 2], hi[K][NCORN / 2];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int pair = 0; pair < NCORN / 2; ++pair) load_pair(tab + (idx[k][2 * pair] & ~1u), lo[k][pair], hi[k][pair]);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int pair = 0; pair < NCORN / 2; ++pair) {
+        const bool odd = idx[k][2 * pair] & 1u;
+        v[k][2 * pair] = odd ? hi[k][pair] : lo[k][pair];
+        v[k][2 * pair + 1] = odd ? lo[k][pair] : hi[k][pair];
+      }
+  } else {
+    TAB t[K][NCORN];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int corner = 0; corner < NCORN; ++corner) t[k][corner] = tab[idx[k][corner]];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int corner = 0; corner < NCORN; ++corner) v[k][corner] = tab_to_f2(t[k][corner]);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < NCORN; ++corner) {
+      const float t0 = mul_nc(v[k][corner].x, wgt[k][corner]), t1 = mul_nc(v[k][corner].y, wgt[k][corner]);
+      a0 = corner == 0 ? t0 : add_nc(a0, t0);
+      a1 = corner == 0 ? t1 : add_nc(a1, t1);
+    }
+    if (p[k] < n) {
+      float* dst = enc + p[k] * ps + (int64_t)l * ls;
+      if (store_sc1) {
+        union { float2 f; uint64_t u; } cv;
+        cv.f = make_float2(a0, a1);
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(dst), cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *reinterpret_cast<float2*>(dst) = make_float2(a0, a1);
+      }
+    }
+  }
+}
+
+// Points per thread in the lattice kernel.  Measured (MI355X): 320x320x10 (1.0 M points): K = 1 0.262, K = 2 0.276,
+// K = 4 0.313 ms - the occupancy lost to the extra registers (8 -> 5 -> 3 waves/SIMD) costs more than the overlap
+// brings; 640x640x20 (8.2 M points): K = 1 1.77, K = 2 1.62 ms.  So: 2 from 4 M points on, else the one-point
+// kernel.  A/B switch (environment, read once): IMMOCO_FWD_K = 1 | 2 | 4.
+static int fwd_points_per_thread(int64_t n) {
+  static const int forced = [] {
+    const char* e = getenv("IMMOCO_FWD_K");
+    const int k = e ? atoi(e) : 0;
+    return (k == 1 || k == 2 || k == 4) ? k : 0;
+  }();
+  return forced ? forced : (n >= (4ll << 20) ? 2 : 1);
+}
+
+template <typename TAB>
+static bool launch_fwd_lat3(const Levels& lv, const Lattice& lat, int64_t n, const TAB* t, float* enc, int64_t ps,
+                            int64_t ls, hipStream_t st) {
+  const int K = fwd_points_per_thread(n);
+  if (lv.dims != 3 || K == 1 || n < 256 * 64) return false;
+  dim3 grid((unsigned)cdiv(n, 256 * K), lv.n_levels);
+  if (K == 2) hashgrid_fwd_lat3_kernel<TAB, 2><<<grid, 256, 0, st>>>(lv, lat, n, t, enc, ps, ls, enc_store_sc1());
+  else hashgrid_fwd_lat3_kernel<TAB, 4><<<grid, 256, 0, st>>>(lv, lat, n, t, enc, ps, ls, enc_store_sc1());
+  return true;
+}
+
 // Measured dead end (round 2): an XCD-scheduled launch - workgroup w runs on XCD w % 8, XCD x encodes ALL points
 // of "its" hashed level (the first eight hashed levels, one each, so that a 4 MB table slice is fetched by ONE L2
 // instead of eight) plus an eighth of the points of every other level - cut the compulsory L2 misses (3.6 M of
@@ -292,6 +410,10 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
     if (rc) return rc;
   }
   const float2* t = reinterpret_cast<const float2*>(table);
+  if (lat && launch_fwd_lat3<float2>(lv, L, n, t, enc, ps, ls, st)) {
+    IMMOCO_LAUNCH_CHECK();
+    return IMMOCO_OK;
+  }
   if (lv.dims == 2) {
     if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
     else hashgrid_fwd_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
@@ -313,6 +435,10 @@ int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, co
   }
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   const __half2* t = reinterpret_cast<const __half2*>(table_half2);
+  if (launch_fwd_lat3<__half2>(lv, lat, n, t, enc, ps, ls, st)) {
+    IMMOCO_LAUNCH_CHECK();
+    return IMMOCO_OK;
+  }
   if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());
   else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());
   IMMOCO_LAUNCH_CHECK();
