@@ -33,6 +33,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -234,6 +235,9 @@ constexpr int EPT = 16;                  // entries per thread per chunk
 // TCP_TCC_READ_REQ) at 137 G/s, half of what immoco_probe_gather sustains with nothing else in flight.  (Issuing
 // the gathers ahead of the next chunk's prefetch - vector-memory results return in issue order - is undone by
 // the compiler, which sinks the last two gathers below the prefetch loads again; no change in the time.)
+// The entry stream is read ONCE: non-temporal loads (`global_load_dwordx4 ... nt`) keep it from displacing the
+// dL/denc window in the XCD's L2 - 0.482 -> 0.464 ms (4 parts), 0.462 -> 0.448 ms (8 parts, but Adam then reads
+// eight partial tables: +0.04 ms).
 template <int DIMS, bool PAIR>  // DIMS names the instantiation (2: image grid, 3: motion grid) in profiles
 __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
                                                       const float2* __restrict__ denc /*[L][n]*/,
                                                       float* __restrict__ dtable, int64_t part_stride,
                                                       int n_tables, int zeroed, const float* __restrict__ f0tab,
-                                                      int n0, uint32_t hw, float inv_hw) {
+                                                      int n0, uint32_t hw, float inv_hw, int nt) {
   constexpr int NS = PAIR ? 4 : 2;                     // sums per run: (even.x, even.y, odd.x, odd.y) or (x, y)
   __shared__ __attribute__((aligned(16))) float accA[2 * SLOTS_PER_ITEM];  // plain stores: one per run
   __shared__ __attribute__((aligned(16))) float accB[2 * SLOTS_PER_ITEM];  // float atomics: the leftovers
@@ -261,9 +265,17 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
   const int lane = tid & 63, wave = tid >> 6;
   const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(entries + it.pe0);
   uint4 q[EPT / 2];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto ld = [&](size_t i) {
+    if (nt) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(e4 + i));
+      return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return e4[i];
+  };
   if ((uint32_t)wave < it.n_wc) {
 #pragma unroll
-    for (int j = 0; j < EPT / 2; ++j) q[j] = e4[(size_t)wave * (WAVE_CHUNK / 2) + j * 64 + lane];
+    for (int j = 0; j < EPT / 2; ++j) q[j] = ld((size_t)wave * (WAVE_CHUNK / 2) + j * 64 + lane);
   }
   auto store_run = [&](uint32_t unit, const float (&v)[NS]) {   // unit: slot (NS = 2) or slot pair (NS = 4)
     if (PAIR) *reinterpret_cast<float4*>(&accA[4 * unit]) = make_float4(v[0], v[1], v[2], v[3]);
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
     }
     if (wc + 4 < it.n_wc) {  // prefetch this wave's next chunk
 #pragma unroll
-      for (int j = 0; j < EPT / 2; ++j) q[j] = e4[(size_t)(wc + 4) * (WAVE_CHUNK / 2) + j * 64 + lane];
+      for (int j = 0; j < EPT / 2; ++j) q[j] = ld((size_t)(wc + 4) * (WAVE_CHUNK / 2) + j * 64 + lane);
     }
     float2 g[EPT];
 #pragma unroll
@@ -607,6 +619,8 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
   const uint32_t hw = (uint32_t)pl->H * (uint32_t)pl->W;
+  // A/B switch (environment, read once): IMMOCO_CSR_STREAM=plain loads the entry stream with ordinary loads
+  static const int nt = [] { const char* e = getenv("IMMOCO_CSR_STREAM"); return (e && strcmp(e, "plain") == 0) ? 0 : 1; }();
   for (size_t r = 0; r < pl->rounds.size(); ++r) {
     const uint32_t first = pl->rounds[r].first, cnt = pl->rounds[r].second;
     if (cnt == 0) continue;
@@ -614,7 +628,7 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
 #define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
   csr_bwd_kernel<D, PAIR><<<cnt, 256, 0, st>>>(n, pl->part_size, pl->items + first, pl->entries,                 \
                                                        (const float2*)denc_level_major, dtable, part_stride,     \
-                                                       pl->n_tables, z, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw)
+                                                       pl->n_tables, z, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw, nt)
     if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);
     else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false);
     else IMMOCO_CSR_BWD(2, false);

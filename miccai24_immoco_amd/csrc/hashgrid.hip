@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
 // arithmetic alone 0.070 ms, no store 0.239, every level gathering from ONE 4 MB slice (no compulsory misses)
 // 0.242, both 0.216 - the pieces add up instead of overlapping, because a wave lives for one (point, level):
 // compute, load, wait, combine, exit.  Same arithmetic per point: bit-identical.
+// (Keeping the wave alive instead - a sequential loop over 2 / 4 / 8 blocks of points per thread, same registers -
+// is SLOWER: 0.274 / 0.317 / 0.434 ms.  Stores and loads share vmcnt on gfx9 and return in order, so the next
+// item's gathers wait behind the write-through store of the previous one; fresh waves do not.)
 template <typename TAB, int K>
 __global__ __launch_bounds__(256) void hashgrid_fwd_lat3_kernel(Levels lv, Lattice lat, int64_t n,
                                                                 const TAB* __restrict__ table,
