@@ -34,6 +34,26 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const V* __restrict__
   out[tid] = acc;
 }
 
+// Diagnostic (environment IMMOCO_PROBE_PATTERN=<cells per pixel>, loads_per_lane is then 4): the address pattern of
+// one fine hashed level of the motion grid - lane = pixel column, the four (y, z) corner pairs of the tcnn hash.
+// Measured: the same 240-268 G loads/s as pseudo-random addresses (4 MB / 2 MB footprint), so the hash pattern itself
+// (L2 channel conflicts) is not what the encode forward loses against the probe.
+template <typename V>
+__global__ __launch_bounds__(256) void probe_hash_kernel(const V* __restrict__ table, uint32_t mask, float cpp,
+                                                         float* __restrict__ out) {
+  const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t z = tid % 320u, y = (tid / 320u) % 320u, m = tid / 102400u;
+  const uint32_t cz = (uint32_t)((float)z * cpp), cy = (uint32_t)((float)y * cpp), cx = m * 7919u;
+  uint32_t j[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    j[u] = (cx ^ ((cy + (u & 1)) * 2654435761u) ^ ((cz + (u >> 1)) * 805459861u)) & mask;
+  V v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = table[j[u]];
+  out[tid] = v[0].x + v[1].x + v[2].x + v[3].x;
+}
+
 }  // namespace immoco
 
 using namespace immoco;
@@ -60,7 +80,12 @@ extern "C" int immoco_probe_gather(int64_t footprint_bytes, int32_t bytes_per_lo
   const unsigned grid = (unsigned)(n_lanes / 256);
   for (int r = 0; r <= repeats; ++r) {        // r == 0: warm-up
     if (r == 1) IMMOCO_CHECK_HIP(hipEventRecord(e0, st));
-    if (bytes_per_load == 16)
+    static const char* pat = getenv("IMMOCO_PROBE_PATTERN");
+    if (pat && bytes_per_load == 16)
+      probe_hash_kernel<float4><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(table), mask, (float)atof(pat), out);
+    else if (pat)
+      probe_hash_kernel<float2><<<grid, 256, 0, st>>>(reinterpret_cast<const float2*>(table), mask, (float)atof(pat), out);
+    else if (bytes_per_load == 16)
       probe_gather_kernel<float4><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(table), mask, loads_per_lane, out);
     else
       probe_gather_kernel<float2><<<grid, 256, 0, st>>>(reinterpret_cast<const float2*>(table), mask, loads_per_lane, out);
