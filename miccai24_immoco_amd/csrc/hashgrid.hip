@@ -99,13 +99,32 @@ static int check_lattice(const Levels& lv, const Lattice& lat, int64_t n) {
   return IMMOCO_OK;
 }
 
-// A/B switch (environment, read once): IMMOCO_ENC_STORE=plain keeps the streamed encoding in L2
+// A/B switch (environment, read once): IMMOCO_ENC_STORE = plain | sc1 | nt (default) - see store_enc().
+// Motion-grid forward at 320x320x10 on one box: plain 0.2667, sc1 0.2618, nt 0.2565 ms.
 static int enc_store_sc1() {
   static const int v = [] {
     const char* e = getenv("IMMOCO_ENC_STORE");
-    return (e && strcmp(e, "plain") == 0) ? 0 : 1;
+    return (e && strcmp(e, "plain") == 0) ? 0 : (e && strcmp(e, "sc1") == 0) ? 1 : 2;
   }();
   return v;
+}
+
+// mode 0: plain store; 1: agent-scope relaxed store = `global_store ... sc1` (write through, line dropped from L2);
+// 2: non-temporal store (`nt`)
+__device__ __forceinline__ void store_enc(float* dst, float2 e, int mode) {
+  if (mode == 1) {
+    union { float2 f; uint64_t u; } cv;
+    cv.f = e;
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(dst), cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (mode == 2) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v;
+    v.x = e.x;
+    v.y = e.y;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(dst));
+  } else {
+    *reinterpret_cast<float2*>(dst) = e;
+  }
 }
 
 // TAB = float2: fp32 table; TAB = __half2: fp16 shadow of the table ("fp16 hash-grid features",
@@ -219,16 +238,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
   load_coords<D, LAT>(coords, lat, p, x);
   const float2 e = encode_point_level<D, TAB>(lv, l, x, table);
   // The encoding streams out (131 MB per launch at 320x320x10) while the gathers want the 4 MB level slice of
-  // the table to STAY in the XCD's 4 MB L2: an agent-scope relaxed store is emitted as `global_store ... sc1`,
-  // which writes through and drops the line from L2 instead of keeping it (MI355X_MICROARCH.md, store flavours).
-  if (store_sc1) {
-    union { float2 f; uint64_t u; } cv;
-    cv.f = e;
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(enc + p * ps + (int64_t)l * ls), cv.u, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    *reinterpret_cast<float2*>(enc + p * ps + (int64_t)l * ls) = e;
-  }
+  // the table to STAY in the XCD's 4 MB L2: a non-temporal store (`global_store ... nt`) does not keep the line
+  // (round 1 used the write-through `sc1` flavour of MI355X_MICROARCH.md for the same reason; nt is 2 % better).
+  store_enc(enc + p * ps + (int64_t)l * ls, e, store_sc1);
 }
 
 // Large 3-D lattices: K points per thread, three phases - indices and weights of all K points, then ALL their
@@ -317,13 +329,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_lat3_kernel(Levels lv, Latti
     }
     if (p[k] < n) {
       float* dst = enc + p[k] * ps + (int64_t)l * ls;
-      if (store_sc1) {
-        union { float2 f; uint64_t u; } cv;
-        cv.f = make_float2(a0, a1);
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(dst), cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        *reinterpret_cast<float2*>(dst) = make_float2(a0, a1);
-      }
+      store_enc(dst, make_float2(a0, a1), store_sc1);
     }
   }
 }
