@@ -630,12 +630,19 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
     const char* e = getenv("IMMOCO_CSR_STREAM");
     return (e && strcmp(e, "plain") == 0) ? 0 : (e && atoi(e) > 0 ? (atoi(e) & 3) : 3);
   }();
+  // Three workgroups per CU instead of the four that 33 KB of LDS would allow (12 KB of unused dynamic LDS): fewer
+  // (part, level) windows in flight per XCD L2.  Isolated kernel, 4 -> 3 per CU: 320x320x10 0.448 -> 0.429 ms (2 per
+  // CU: 0.438; graph iteration 1.337 -> 1.322), 320x320x20 0.837 -> 0.800, 256x256x8 0.252 -> 0.241, 160x160x10
+  // unchanged; plans that run as several rounds (launches of 8 parts) lose instead - 480x480x10 1.25 -> 1.33,
+  // 640x640x20 3.54 -> 3.65 - and keep four.  A/B switch (environment, read once): IMMOCO_CSR_PAD_LDS=<bytes>.
+  static const int pad_env = [] { const char* e = getenv("IMMOCO_CSR_PAD_LDS"); return e ? atoi(e) : -1; }();
+  const int pad_lds = pad_env >= 0 ? pad_env : (pl->rounds.size() == 1 ? 12288 : 0);
   for (size_t r = 0; r < pl->rounds.size(); ++r) {
     const uint32_t first = pl->rounds[r].first, cnt = pl->rounds[r].second;
     if (cnt == 0) continue;
     const int z = r == 0 ? zeroed : 0;  // later rounds add to the tiles the first one has written
 #define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
-  csr_bwd_kernel<D, PAIR><<<cnt, 256, 0, st>>>(n, pl->part_size, pl->items + first, pl->entries,                 \
+  csr_bwd_kernel<D, PAIR><<<cnt, 256, pad_lds, st>>>(n, pl->part_size, pl->items + first, pl->entries,                 \
                                                        (const float2*)denc_level_major, dtable, part_stride,     \
                                                        pl->n_tables, z, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw, nt)
     if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);

@@ -156,6 +156,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------
 // backward
+// Measured dead end (round 2): the wide net (HID = 256: 448 registers, 105 KB of LDS, 1 wave/SIMD - a workgroup
+// excludes every other kernel from its CU, and beside the motion grid's encode backward it takes 0.52 ms instead of
+// 0.14) split into two hidden-layer halves per point tile (grid.y = 2, 248 registers, 71 KB, the halves ADD their
+// d enc into a zeroed buffer): 0.155 ms alone instead of 0.148, still 0.47 ms beside the encode backward (whose four
+// 33 KB workgroups per CU leave no 71 KB hole), and the 13 MB memset costs the image chain another 0.06 ms:
+// graph iteration 1.353 instead of 1.346 ms.  Not kept.
 template <int HID, int ACT>
 __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(const float* in /* may alias din */, int64_t ps, int64_t ls,
                                                            int64_t n, const float* __restrict__ w1,
