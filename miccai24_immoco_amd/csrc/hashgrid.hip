@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(Levels lv, const floa
 // (Keeping the wave alive instead - a sequential loop over 2 / 4 / 8 blocks of points per thread, same registers -
 // is SLOWER: 0.274 / 0.317 / 0.434 ms.  Stores and loads share vmcnt on gfx9 and return in order, so the next
 // item's gathers wait behind the write-through store of the previous one; fresh waves do not.)
+// Occupancy: the one-point kernel (42 registers, 8 waves/SIMD) only loses when workgroups per CU are capped with
+// unused LDS - 8 per CU 0.2555 ms, 6: 0.263, 5: 0.270, 4: 0.2825, 3: 0.301 - unlike the encode backward (csr.hip).
 template <typename TAB, int K>
 __global__ __launch_bounds__(256) void hashgrid_fwd_lat3_kernel(Levels lv, Lattice lat, int64_t n,
                                                                 const TAB* __restrict__ table,
