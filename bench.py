@@ -219,8 +219,8 @@ def main():
                           "hip_psnr_db": [round(p, 3) for p in hip], "hip_timed_run_psnr_db": round(psnr[0], 3),
                           "oracle_psnr_db": ref_rec["oracle_psnr_db"], "oracle_source": ref_rec["source"],
                           "note": "mean over 8 HIP runs minus mean over the oracle records; single HIP runs have a standard "
-                                  "deviation of 1.75 dB once lambda_GE has underflowed to 0 at iteration 1500 (24 runs: mean "
-                                  "34.94 dB vs the six oracle records' 34.62, profiles/r02_c2_end_psnr_24runs.txt; DESIGN.md 2)"}
+                                  "deviation of 1.75 dB once lambda_GE has underflowed to 0 at iteration 1500 (64 runs: mean "
+                                  "34.96 dB vs the six oracle records' 34.62, profiles/r02_c2_end_psnr_{24,40}runs.txt; DESIGN.md 2)"}
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
         solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16)
         sl = slices[0]
