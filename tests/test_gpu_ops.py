@@ -1057,7 +1057,9 @@ def test_solver_config5_shape_and_precision_vs_oracle_record(env, golden):
     assert np.isfinite(a).all() and a[-1] < a[0]
     np.testing.assert_allclose(a[:3], b[:3], rtol=1e-4)
     np.testing.assert_allclose(a[:5], b[:5], rtol=2e-3)       # two fp32 summation orders: 1.6e-4 apart at iteration 4
-    assert abs(a[0] - lf[0]) <= 1e-2 * a[0] and a[0] != lf[0]        # fp16 features: close to, not equal to, fp32
+    # fp16 features: close to, not equal to, fp32 (the FIRST losses can coincide after rounding to fp32: the initial
+    # tables are +-1e-4, their fp16 rounding error is below the loss's ulp)
+    assert abs(a[0] - lf[0]) <= 1e-2 * a[0] and not np.array_equal(a[:5].astype(np.float64), lf[:5])
 
 
 def test_batch_of_slices_independent(env):
