@@ -247,9 +247,9 @@ def main():
         # Dominant kernel: the motion grid's encode backward, timed with HIP events on the solver's stream.
         # `kernel_ms` (used for `achieved`) is its average over a serial eager pass of the iteration
         # (immoco_solver_profile) - the figure rocprofv3's kernel stats of this command report too
-        # (profiles/*kernel_stats*: 0.527 ms vs 0.533 ms here); `kernel_ms_concurrent` is the same kernel
-        # between event markers while the image-INR chain runs beside it on the second stream, as in the
-        # replayed graph (the tracer serialises differently, so that figure has no rocprof counterpart).
+        # (profiles/r02_final_kernel_stats*: 0.426 ms vs 0.430 ms here); `kernel_ms_concurrent` is the same kernel
+        # between event markers in an EAGER pass with the image-INR chain beside it on the second stream (in the
+        # replayed graph the wide MLP backward arrives later and the kernel runs at its isolated speed).
         name = "motion_encode_bwd"
         ms = dict(phases)[name]
         ms_conc = dom_ms if dom_ms > 0 else ms
