@@ -502,9 +502,46 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
     }
   }
   {
+    // The consumer (Adam) visits the listed slot ranges only.  A touched 2048-slot block is listed whole unless at
+    // most half of its 32-slot granules receive anything - tiny-cuda-nn's wrapped-stride levels 12-15 of a 2-D grid
+    // spread a few thousand distinct slots evenly over all 256 blocks of the level (image grid at 320x320: 10, 5, 2.5
+    // and 1.25 slots per block) - then only the occupied granules are listed, as runs.  (Twin entries are counted on
+    // the even slot of their pair; a granule is even-aligned, so it holds both.)
+    constexpr uint32_t GRAN = 32;
     std::vector<uint2> tv;
     tv.reserve(touched.size());
-    for (const auto& kv : touched) tv.push_back(make_uint2(kv.first, kv.second));
+    for (int l = 0; l < lv.n_levels; ++l) {
+      for (uint32_t sb = 0; sb < lv.size[l]; sb += SLOTS_PER_ITEM) {
+        const auto itb = touched.find(lv.offset[l] + sb);
+        if (itb == touched.end()) continue;
+        const uint32_t ns = itb->second & 0x7FFFFFFFu, flag = itb->second & 0x80000000u;
+        const uint32_t n_gran = (ns + GRAN - 1) / GRAN;
+        std::vector<char> occ(n_gran, 0);
+        uint32_t k = 0;
+        for (uint32_t g = 0; g < n_gran; ++g) {
+          const uint32_t a = sb + g * GRAN, b = sb + std::min(ns, (g + 1) * GRAN);
+          for (int q = 0; q < NP && !occ[g]; ++q) {
+            const size_t cb = (size_t)lv.offset[l] * NP + (size_t)q * lv.size[l];
+            occ[g] = h_offs[cb + b] != h_offs[cb + a];
+          }
+          k += occ[g];
+        }
+        if (2 * k > n_gran || (ns % GRAN) != 0) {
+          tv.push_back(make_uint2(lv.offset[l] + sb, ns | flag));
+          continue;
+        }
+        for (uint32_t g = 0; g < n_gran;) {
+          if (!occ[g]) {
+            ++g;
+            continue;
+          }
+          uint32_t e = g;
+          while (e < n_gran && occ[e]) ++e;
+          tv.push_back(make_uint2(lv.offset[l] + sb + g * GRAN, ((e - g) * GRAN) | flag));
+          g = e;
+        }
+      }
+    }
     pl->n_touched = (uint32_t)tv.size();
     IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->touched, std::max<size_t>(1, tv.size()) * sizeof(uint2)));
     IMMOCO_CHECK_HIP(hipMemcpyAsync(pl->touched, tv.data(), tv.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
