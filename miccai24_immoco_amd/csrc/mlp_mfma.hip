@@ -335,20 +335,25 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
       }
     }
   }
-  if (wave_id >= n_tiles) return;  // this wave had no tile
-  // ---- flush the weight gradients (once per wave): transpose dW1^T tiles through LDS so that every
-  // atomic wave-instruction covers 256 contiguous bytes of dW1[j][k]
+  const bool has_tile = wave_id < n_tiles;  // a wave without tiles holds zeros and only helps with the reduction
+  // ---- flush the weight gradients (once per WORKGROUP): the four waves transpose their dW1^T tiles into their LDS
+  // regions, every wave sums a quarter of the 32x32 tile over the four regions and adds it with 256-byte contiguous
+  // atomics - a quarter of the atomics of a per-wave flush (the wide net's 1024 waves sent 33 MB of them per launch
+  // at a 32 KB target: rocprofv3 WRITE_SIZE 46 MB for 13 MB of d enc)
 #pragma unroll
   for (int jt = 0; jt < NJT; ++jt) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();   // the tiles are free (main loop / previous round)
 #pragma unroll
     for (int g = 0; g < 16; ++g) tr[r * TLD + drow(g, h)] = dw1t[jt][g];  // [hidden r][feature k]
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * 64 + lane;  // (hidden = idx>>5, feature = idx&31) of this 32x32 tile
-      unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, tr[(idx >> 5) * TLD + (idx & 31)]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = (4 * wave + k) * 64 + lane;  // (hidden = idx>>5, feature = idx&31) of this 32x32 tile
+      const int off = (idx >> 5) * TLD + (idx & 31);
+      const float v = (tr_all[off] + tr_all[2 * 32 * TLD + off]) + (tr_all[4 * 32 * TLD + off] + tr_all[6 * 32 * TLD + off]);
+      unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, v);
     }
+    if (!has_tile) continue;
     if (LANE_DW2) {
       // sum the per-lane partials over the 32 points of each lane half, stage the 2 x 32 sums in LDS and
       // flush them with two 128-byte atomics (one atomic per (hidden, output) pair - 64 two-lane
