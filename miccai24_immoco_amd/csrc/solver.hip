@@ -312,32 +312,28 @@ std::vector<Step> arrange(const std::vector<Step>& all, Order o) {
 
 // A graph executable must outlive its queued launches: a solve that needs a new capture (other slice, other
 // buffers) parks the old one behind an event on the stream instead of destroying it under the GPU's feet.
+// A replaced graph executable may still have launches queued, and the runtime runs its forked branches on streams of
+// its own: destroying it as soon as an event on the solver's stream had completed crashed once in ~15 runs of the
+// 64-slice batch test (SIGSEGV in the host process, a recapture every 16 ms).  Retired executables are therefore kept
+// until the whole device is idle: at the latest when RETIRED_MAX of them have piled up (a device synchronise: the
+// host is that far ahead of the GPU only in batch solves), and when the solver is destroyed or re-planned.
+constexpr size_t RETIRED_MAX = 16;
 void retire_graph(immoco_solver* s) {
   for (hipGraphExec_t* g : {&s->gexec, &s->gexec2}) {
     if (!*g) continue;
-    hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, s->stream) == hipSuccess) {
-      s->retired.emplace_back(*g, ev);
-    } else {  // fall back to draining the stream
-      (void)hipStreamSynchronize(s->stream);
-      hipGraphExecDestroy(*g);
-      if (ev) hipEventDestroy(ev);
-    }
+    s->retired.emplace_back(*g, nullptr);
     *g = nullptr;
   }
 }
 void sweep_retired(immoco_solver* s, bool wait) {
-  for (size_t i = 0; i < s->retired.size();) {
-    if (wait) (void)hipEventSynchronize(s->retired[i].second);
-    if (hipEventQuery(s->retired[i].second) == hipSuccess) {
-      hipGraphExecDestroy(s->retired[i].first);
-      hipEventDestroy(s->retired[i].second);
-      s->retired.erase(s->retired.begin() + i);
-    } else {
-      ++i;
-    }
+  if (s->retired.empty() || (!wait && s->retired.size() < RETIRED_MAX)) return;
+  (void)hipDeviceSynchronize();
+  for (auto& r : s->retired) {
+    hipGraphExecDestroy(r.first);
+    if (r.second) hipEventDestroy(r.second);
   }
-  (void)hipGetLastError();  // hipErrorNotReady of the query is not an error
+  s->retired.clear();
+  (void)hipGetLastError();
 }
 
 int run_steps(const std::vector<Step>& steps, hipStream_t q) {
@@ -511,9 +507,8 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   s->lanes.clear();
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->side) (void)hipStreamSynchronize(s->side);
-  if (s->gexec) hipGraphExecDestroy(s->gexec);
-  if (s->gexec2) hipGraphExecDestroy(s->gexec2);
-  sweep_retired(s, true);
+  retire_graph(s);
+  sweep_retired(s, true);   // device idle, then the executables go
   if (s->parent) {  // a lane borrows lattices and plans from its parent
     s->plan_img = s->plan_mot = nullptr;
     s->xs = s->ys = s->ms = nullptr;
