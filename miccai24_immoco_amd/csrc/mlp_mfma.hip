@@ -75,20 +75,27 @@ __device__ __forceinline__ void load_enc_b(const float* in, int64_t ps, int64_t 
 
 // LDS weight fragments: AW[jt][s4][lane] float4 = W1[jt*32 + r][2*(4*s4+i) + h], i = 0..3
 //                       AWT[jt][g4][lane] float4 = W1[jt*32 + drow(4*g4+i, h)][r]
+// W1 is read with coalesced 16-byte loads and every element is SCATTERED to its fragment positions in LDS (the
+// gather formulation - fragment entry by fragment entry, 64 different cache lines per load instruction - cost the
+// wide backward ~13 us per workgroup, a tenth of its run time).  Element W1[j][k], j = jt*32 + rho:
+//   AW : entry (jt*4 + s4)*64 + (h*32 + rho),  component i,  with k = 2*(4*s4 + i) + h
+//   AWT: entry (jt*4 + g4)*64 + (h'*32 + k),   component i', with rho = drow(4*g4 + i', h'), i.e. h' = (rho>>2)&1,
+//        g4 = rho>>3, i' = rho&3
 template <int HID>
 __device__ __forceinline__ void build_weight_frags(const float* __restrict__ w1, float4* aw, float4* awt, int tid) {
-  constexpr int NJT = HID / 32;
-  for (int e = tid; e < NJT * 4 * 64; e += 256) {
-    const int lane = e & 63, q4 = (e >> 6) & 3, jt = e >> 8;
-    const int r = lane & 31, h = lane >> 5;
-    float v[4], t[4];
+  float* awf = reinterpret_cast<float*>(aw);
+  float* awtf = reinterpret_cast<float*>(awt);
+  for (int e4 = tid; e4 < HID * 32 / 4; e4 += 256) {
+    const float4 q = reinterpret_cast<const float4*>(w1)[e4];   // W1[j][k0 .. k0+3]
+    const float v[4] = {q.x, q.y, q.z, q.w};
+    const int j = e4 >> 3, k0 = (e4 & 7) * 4;
+    const int jt = j >> 5, rho = j & 31;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i] = w1[(jt * 32 + r) * 32 + 2 * (4 * q4 + i) + h];
-      t[i] = w1[(jt * 32 + drow(4 * q4 + i, h)) * 32 + r];
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c, sidx = k >> 1, h = k & 1;
+      awf[(((jt * 4 + (sidx >> 2)) * 64) + h * 32 + rho) * 4 + (sidx & 3)] = v[c];
+      if (awt) awtf[(((jt * 4 + (rho >> 3)) * 64) + ((rho >> 2) & 1) * 32 + k) * 4 + (rho & 3)] = v[c];
     }
-    aw[e] = make_float4(v[0], v[1], v[2], v[3]);
-    if (awt) awt[e] = make_float4(t[0], t[1], t[2], t[3]);
   }
 }
 
