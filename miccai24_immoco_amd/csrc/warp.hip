@@ -498,7 +498,11 @@ int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, 
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     // enough workgroups to fill the chip: split the motion groups into chunks
     int chunks = 1;
-    while (chunks < nM && (int64_t)tiles_x * tiles_y * chunks < 768) ++chunks;
+    // (the kernel is latency-bound: 320x320x10 with 10 / 5 / 3 / 2 / 1 motion groups per workgroup takes 0.063 / 0.061 /
+    // 0.056 / 0.054 / 0.061 ms - more, shorter workgroups until the per-workgroup window flush dominates.  A/B switch
+    // (environment, read once): IMMOCO_WARP_BLOCKS = minimum number of workgroups.)
+    static const int min_blocks = [] { const char* e = getenv("IMMOCO_WARP_BLOCKS"); return e ? atoi(e) : 2000; }();
+    while (chunks < nM && (int64_t)tiles_x * tiles_y * chunks < min_blocks) ++chunks;
     const int mpc = (nM + chunks - 1) / chunks;
     chunks = (nM + mpc - 1) / mpc;
     dim3 grid(tiles_x * tiles_y, chunks);
