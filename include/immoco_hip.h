@@ -123,6 +123,19 @@ int immoco_mlp_bwd(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_
                    const float* dout /*[n][n_out]*/, float* din, float* dw1, float* dw2,
                    void* stream);
 
+/* The same MLP in tiny-cuda-nn's OWN network precision (the reference instantiates FullyFusedMLP / CutlassMLP with
+ * __half, /root/reference/src/models/immoco.py:11-25,60-65; tcnn torch binding: loss_scale 128): fp16 OPERANDS -
+ * the encoding, W1, the hidden activations, W2, dout * loss_scale, dL/dpre - with fp32 accumulation on
+ * v_mfma_f32_32x32x16_f16; buffers stay fp32 (weights are rounded on the fly), outputs / din / dw1 / dw2 are fp32
+ * and unscaled.  Same layouts and accumulate semantics as immoco_mlp_fwd / immoco_mlp_bwd. */
+int immoco_mlp_fwd_half(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                        int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                        float* out, void* stream);
+int immoco_mlp_bwd_half(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                        int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                        const float* dout /*[n][n_out]*/, float loss_scale, float* din, float* dw1,
+                        float* dw2, void* stream);
+
 /* ---- parameter init (tcnn: encoding U(-1e-4,1e-4), MLP Xavier-uniform on the
  *      padded shapes; counter-based generator shared bit-exactly with the oracle) */
 int immoco_init_params(const immoco_grid_cfg* grid, const immoco_mlp_cfg* mlp, uint32_t seed,
@@ -227,7 +240,10 @@ typedef struct immoco_solver_cfg {
                              with the streams on separate hardware queues (GPU_MAX_HW_QUEUES=12): 2 lanes 1.55,
                              3 lanes 1.65 ms per slice-iteration against 1.36 serial - two slices' hash-grid
                              gathers evict each other's 4 MB level slices from the XCD L2s */
-  int32_t reserved[2];
+  int32_t mlp_fp16;       /* 1: both MLPs in tiny-cuda-nn's network precision (immoco_mlp_fwd_half / _bwd_half: fp16
+                             operands, fp32 accumulation, loss scale 128); with table_fp16 this is "tcnn's own
+                             arithmetic" (immoco.py:11-25,60-65).  default 0: exact fp32 on the f32 MFMA */
+  int32_t reserved[1];
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;

@@ -45,7 +45,7 @@ class SolverCfg(C.Structure):
                 ("image_mlp", MlpCfg), ("motion_mlp", MlpCfg),
                 ("use_graph", C.c_int32), ("atomic_scatter", C.c_int32), ("grad_parts", C.c_int32),
                 ("serial_chains", C.c_int32), ("table_fp16", C.c_int32),
-                ("batch_lanes", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("batch_lanes", C.c_int32), ("mlp_fp16", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 _P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
@@ -62,6 +62,8 @@ PROTOTYPES = {
     "immoco_hashgrid_bwd": (C.c_int, [_GP, _P, _I64, _P, _I64, _I64, _P, _P]),
     "immoco_mlp_fwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "immoco_mlp_bwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "immoco_mlp_fwd_half": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "immoco_mlp_bwd_half": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _F, _P, _P, _P, _P]),
     "immoco_init_params": (C.c_int, [_GP, _MP, _U32, _P, _P]),
     "immoco_warp_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "immoco_warp_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),

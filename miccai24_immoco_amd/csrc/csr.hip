@@ -180,7 +180,8 @@ struct BwdItem {
   uint32_t e0, e1;       // range in the slot-sorted build array (plan build only)
   uint32_t s0, ns;       // first global slot (block aligned within its level), number of slots
   uint32_t level;
-  uint32_t part_shared;  // part | (shared << 16): shared = the slot block also belongs to other items
+  uint32_t part_shared;  // part | (shared << 16) | (first << 17): shared = the slot block also belongs to other items
+                         // of the same part; first = no earlier item (of any round) writes this (table, slot block)
   uint32_t pe0, n_wc;    // start (in entries, multiple of 1024) and wave-chunk count in the final array
 };
 
@@ -374,15 +375,18 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
   }
   __syncthreads();
   float* __restrict__ out = dtable + (size_t)(part % (uint32_t)n_tables) * part_stride + (size_t)it.s0 * 2;
-  if (it.part_shared >> 16) {
+  if ((it.part_shared >> 16) & 1u) {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
       const float v = accA[i] + accB[i];
       if (v != 0.f) unsafeAtomicAdd(out + i, v);
     }
-  } else if (zeroed) {
-    // exclusive owner of these (part, slot) pairs: no atomics.  Solver mode (`zeroed`): the tile is
-    // OVERWRITTEN every iteration (zeros included), so nobody has to clear it (Adam's fused
-    // zero_grad skips these ranges: 16 B/param less HBM traffic); op-level mode accumulates.
+  } else if (zeroed && ((it.part_shared >> 17) & 1u)) {
+    // exclusive owner of these (part, slot) pairs: no atomics.  Solver mode (`zeroed`): the FIRST writer of a
+    // (table, slot block) over all rounds OVERWRITES the tile every iteration (zeros included), so nobody has
+    // to clear it (Adam's fused zero_grad skips these ranges: 16 B/param less HBM traffic); later writers
+    // (other parts of later rounds) and op-level mode accumulate.  The first writer is decided per ITEM at
+    // plan build, not per round: a block whose only items sit in a later round (the wrapped-stride levels
+    // index by the m cell, so different rounds hit different blocks) would otherwise accumulate for ever.
     if (nt & 2) {
       for (int i = tid; i < 2 * (int)it.ns; i += 256) __builtin_nontemporal_store(accA[i] + accB[i], out + i);
     } else {
@@ -578,6 +582,17 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
     }
     pl->rounds.emplace_back((uint32_t)begin, (uint32_t)(items.size() - begin));
   }
+  // first writer of every (table, slot block), in launch order (rounds are stream-ordered; inside a round a
+  // (table, block) pair has one part, and a block that is split over several items is `shared`: atomics into a
+  // tile that the consumer clears)
+  {
+    std::map<uint64_t, char> seen;
+    for (BwdItem& it : items) {
+      if (it.e1 == it.e0) continue;  // padding item
+      const uint64_t key = ((uint64_t)((it.part_shared & 0xFFFFu) % (uint32_t)NT) << 32) | it.s0;
+      if (seen.emplace(key, 1).second) it.part_shared |= 1u << 17;
+    }
+  }
   // final (padded, transposed) positions
   uint64_t total = 0;
   for (BwdItem& it : items) {
@@ -677,11 +692,10 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
   for (size_t r = 0; r < pl->rounds.size(); ++r) {
     const uint32_t first = pl->rounds[r].first, cnt = pl->rounds[r].second;
     if (cnt == 0) continue;
-    const int z = r == 0 ? zeroed : 0;  // later rounds add to the tiles the first one has written
 #define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
   csr_bwd_kernel<D, PAIR><<<cnt, 256, pad_lds, st>>>(n, pl->part_size, pl->items + first, pl->entries,                 \
                                                        (const float2*)denc_level_major, dtable, part_stride,     \
-                                                       pl->n_tables, z, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw, nt)
+                                                       pl->n_tables, zeroed, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw, nt)
     if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);
     else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false);
     else IMMOCO_CSR_BWD(2, false);

@@ -38,6 +38,14 @@ int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
                         const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                         hipStream_t st, int64_t dout_plane = 0);
 
+// mlp_f16.hip — tiny-cuda-nn's operand precision: fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16);
+// the backward scales dout by `scale` (tcnn's loss scale, 128) before rounding it to fp16
+int launch_mlp_fwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                       const float* w1, const float* w2, float* out, hipStream_t st);
+int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                       const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
+                       hipStream_t st, int64_t dout_plane, float scale);
+
 // warp.hip
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st);
 int launch_warp_bwd(const float* image, const float* grids, const float* dout, int nM, int H, int W,

@@ -18,6 +18,9 @@ namespace immoco {
 
 __global__ void tick_kernel(int32_t* it) { *it += 1; }
 
+// tiny-cuda-nn's torch binding scales dL/dout by 128 before the fp16 backward; cfg.mlp_fp16 does too
+constexpr float TCNN_LOSS_SCALE = 128.f;
+
 // branch 0: serial section on the main stream; branch 1 / 2: two independent chains that run
 // concurrently (main / side stream) between a fork and the next serial step (join).  The image-INR
 // kernels are small grids (102 400 points) that cannot fill 256 CUs on their own; they overlap with
@@ -136,6 +139,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
                   }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
+                    if (s->cfg.mlp_fp16)
+                      return launch_mlp_fwd_f16(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
                   }, 1});
   }
@@ -146,6 +151,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, 2, 2 * P, q);
                 }, 2});
   st.push_back({"image_mlp_fwd", [=](hipStream_t q) {
+                  if (s->cfg.mlp_fp16)
+                    return launch_mlp_fwd_f16(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
                   return launch_mlp_fwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
                 }, 2});
   st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }, 2});
@@ -181,6 +188,9 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                                   s->o_mot, q);
                   }});
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
+                    if (s->cfg.mlp_fp16)
+                      return launch_mlp_bwd_f16(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
+                                                s->enc_mot, g_w1m, g_w2m, q, 0, TCNN_LOSS_SCALE);
                     return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
                                           s->enc_mot, g_w1m, g_w2m, q);
                   }});  // before the fork: the image chain's MFMA-bound MLP backward then runs beside the
@@ -197,6 +207,9 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // the rocprofv3 stats - and slows that gather from 0.45 to 0.58 ms; run BEFORE the fork instead, alone, the
   // iteration takes 1.435 ms instead of 1.351: the overlap is still worth more than it costs.)
   st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
+                  if (s->cfg.mlp_fp16)
+                    return launch_mlp_bwd_f16(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage,
+                                              s->enc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE);
                   return launch_mlp_bwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
                                         g_w1i, g_w2i, q, /*planar dimage*/ P);
                 }, 2});
@@ -731,7 +744,16 @@ extern "C" int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const flo
         adam_motion ? adam_motion + 2 * i * s->n_params_mot : nullptr, iters, lr, lambda_sched, step0,
         out_image ? out_image + i * P2 : nullptr, out_kspace ? out_kspace + i * P2 : nullptr,
         loss_hist ? loss_hist + (int64_t)i * iters : nullptr, stream, i < n_lanes, false);
-    if (rc) return rc;
+    if (rc) {
+      // lanes that already have slices queued still read and write the caller's buffers: order the caller's
+      // stream after them before the error goes back (the error string of `rc` is kept)
+      for (int k = 0; k < n_lanes && k <= i; ++k) {
+        immoco_solver* l = k == 0 ? s : s->lanes[k - 1];
+        if (hipEventRecord(l->ev_out, l->stream) == hipSuccess) (void)hipStreamWaitEvent(as_stream(stream), l->ev_out, 0);
+      }
+      (void)hipGetLastError();
+      return rc;
+    }
   }
   for (int k = 0; k < n_lanes && k < B; ++k) {
     int rc = leave(k == 0 ? s : s->lanes[k - 1], as_stream(stream));

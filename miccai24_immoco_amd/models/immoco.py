@@ -147,15 +147,15 @@ class _SolverHandle:
     """RAII wrapper of immoco_solver_t; cached per (device, H, W, nM)."""
 
     def __init__(self, device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, table_fp16=False,
-                 batch_lanes=0):
+                 batch_lanes=0, mlp_fp16=False, serial_chains=False):
         self.device, self.H, self.W, self.nM = device, H, W, nM
         self.image_grid = L.grid_cfg(2, encoding_config)
         self.motion_grid = L.grid_cfg(3, encoding_config)
         self.image_mlp = L.mlp_cfg(32, 2, network_config)
         self.motion_mlp = L.mlp_cfg(32, 2, mot_network_config)
         cfg = L.SolverCfg(H, W, nM, self.image_grid, self.motion_grid, self.image_mlp, self.motion_mlp,
-                          1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts), 0, 1 if table_fp16 else 0,
-                          int(batch_lanes))
+                          1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts),
+                          1 if serial_chains else 0, 1 if table_fp16 else 0, int(batch_lanes), 1 if mlp_fp16 else 0)
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(L.lib().immoco_solver_create(C.byref(cfg), C.byref(self.handle)), "solver_create")
@@ -261,16 +261,16 @@ _SOLVERS = {}
 
 
 def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, instance=0,
-               table_fp16=False, batch_lanes=0) -> _SolverHandle:
+               table_fp16=False, batch_lanes=0, mlp_fp16=False, serial_chains=False) -> _SolverHandle:
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance),
-           bool(table_fp16), int(batch_lanes))
+           bool(table_fp16), int(batch_lanes), bool(mlp_fp16), bool(serial_chains))
     s = _SOLVERS.get(key)
     if s is None:
         s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts, table_fp16,
-                                          batch_lanes)
+                                          batch_lanes, mlp_fp16, serial_chains)
     return s
 
 
@@ -294,7 +294,8 @@ def lambda_schedule(iters, lambda_ge, rule="immoco"):
 
 def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2, debug=False,
                              *, seed=1337, norm_scale=16000.0, lambda_rule="immoco", return_loss=False,
-                             use_graph=True, atomic_scatter=False, grad_parts=0, instance=0, table_fp16=False):
+                             use_graph=True, atomic_scatter=False, grad_parts=0, instance=0, table_fp16=False,
+                             mlp_fp16=False):
     """IM-MoCo per-slice solve (immoco.py:116-206).
 
     Args mirror the reference: ``kspace_corr`` [H, W] complex (any device), ``masks`` [nM, H, W]
@@ -306,13 +307,15 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
     ordered after it on the caller's stream); ``instance`` selects one of several solver handles of
     the same shape, so that independent slices can be in flight concurrently on one GPU;
     ``table_fp16=True`` gathers the hash-grid features from fp16 shadows of the fp32 master tables
-    (tiny-cuda-nn's own precision; BASELINE config 5).
+    (tiny-cuda-nn's own precision; BASELINE config 5); ``mlp_fp16=True`` runs both MLPs with fp16 operands and
+    fp32 accumulation (tcnn's network precision, loss scale 128) instead of exact fp32.
     """
     L.require_gpu(masks, what="imcoco_motion_correction(masks)")
     dev = masks.device
     nM, H, W = masks.shape
     lambdas = lambda_schedule(iters, lambda_ge, lambda_rule)   # raises ZeroDivisionError like the reference
-    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts, instance, table_fp16)
+    solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts, instance, table_fp16,
+                        mlp_fp16=mlp_fp16)
     k = kspace_corr.to(dev).to(torch.complex64).contiguous()
     if k.shape != (H, W):
         raise L.ImmocoError(f"kspace_corr shape {tuple(k.shape)} does not match masks {(H, W)}")
@@ -339,7 +342,7 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
 
 def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate=1e-2, lambda_ge=1e-2, *, seed=1337,
                                    norm_scale=16000.0, lambda_rule="immoco", return_loss=False, use_graph=True,
-                                   table_fp16=False, lanes=1):
+                                   table_fp16=False, lanes=1, mlp_fp16=False):
     """``imcoco_motion_correction`` for a batch (BASELINE config 3: B slices resident on one GPU):
     ``kspaces [B, H, W] c64`` and one ``masks [nM_i, H, W]`` per slice.  Slices with the same number of
     movement groups share one ``immoco_solver_solve_batch`` call (parameters, Adam state and outputs live in
@@ -362,7 +365,7 @@ def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate
             raise L.ImmocoError(f"masks[{i}] shape {tuple(m.shape)} does not match kspaces {(H, W)}")
         by_nm.setdefault(int(m.shape[0]), []).append(i)
     for nM, idx in sorted(by_nm.items()):
-        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16, lanes)
+        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16, lanes, mlp_fp16=mlp_fp16)
         Bg = len(idx)
         k = kspaces[idx].to(torch.complex64).contiguous()
         kin = torch.empty_like(k)

@@ -4,8 +4,10 @@ Mirrors the third-party operator the reference path sits behind
 (reference src/models/immoco.py:1,60-65,85,93): same constructor arguments, a
 single flat fp32 ``params`` Parameter ([W1 | W2(padded) | hash table], tcnn
 order), ``forward(x[N, n_in]) -> [N, n_out]``.  Differences, by design: compute
-and output are fp32 (tcnn: fp16 with loss scale 128), and the initial values
-come from the library's counter-based generator instead of tcnn's RNG stream.
+and output are fp32 by default (tcnn: fp16 with loss scale 128; ``mlp_fp16=True``
+selects tcnn's operand precision for the network: fp16 operands, fp32
+accumulation, loss scale 128), and the initial values come from the library's
+counter-based generator instead of tcnn's RNG stream.
 
 Backward of the encoding: the reference always passes the same lattice tensor
 (``identy_grid.view(-1, 2)`` / ``input_grid``, immoco.py:72-80,85,93).  When the
@@ -86,6 +88,7 @@ class _INRFunction(torch.autograd.Function):
     def forward(ctx, x, params, mod):
         L.require_gpu(x, params, what="NetworkWithInputEncoding")
         key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)   # of the caller's tensor
+        x_caller = x
         x = x.contiguous().float()
         n = x.shape[0]
         w1, w2, tab = mod._split(params)
@@ -93,7 +96,7 @@ class _INRFunction(torch.autograd.Function):
         enc = torch.empty((mod.grid_cfg.n_levels, n, 2), device=x.device, dtype=torch.float32)
         out = torch.empty((n, 2), device=x.device, dtype=torch.float32)
         lib, st = L.lib(), L.stream_ptr()
-        plan = mod._plan_for(x, key)
+        plan = mod._plan_for(x, key, x_caller)
         if plan is not None:      # the reference's lattice: per-axis kernel (bit-identical, fewer cache lines)
             L.check(lib.immoco_hashgrid_fwd_lattice(C.byref(mod.grid_cfg), plan.nM, plan.H, plan.W, L.ptr(plan.axes[0]),
                                                     L.ptr(plan.axes[1]), L.ptr(plan.axes[2]), L.ptr(tab), L.ptr(enc),
@@ -101,8 +104,8 @@ class _INRFunction(torch.autograd.Function):
         else:
             L.check(lib.immoco_hashgrid_fwd(C.byref(mod.grid_cfg), L.ptr(x), n, L.ptr(tab), L.ptr(enc), 2, 2 * n, st),
                     "hashgrid_fwd")
-        L.check(lib.immoco_mlp_fwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(out), st),
-                "mlp_fwd")
+        mlp_fwd = lib.immoco_mlp_fwd_half if mod.mlp_fp16 else lib.immoco_mlp_fwd
+        L.check(mlp_fwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(out), st), "mlp_fwd")
         ctx.mod = mod
         ctx.plan = plan
         ctx.save_for_backward(x, params, enc)
@@ -119,8 +122,13 @@ class _INRFunction(torch.autograd.Function):
         dw1, dw2, dtab = mod._split(dparams)
         denc = torch.empty_like(enc)
         lib, st = L.lib(), L.stream_ptr()
-        L.check(lib.immoco_mlp_bwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(dout),
-                                   L.ptr(denc), L.ptr(dw1), L.ptr(dw2), st), "mlp_bwd")
+        if mod.mlp_fp16:
+            L.check(lib.immoco_mlp_bwd_half(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2),
+                                            L.ptr(dout), float(mod.loss_scale), L.ptr(denc), L.ptr(dw1), L.ptr(dw2), st),
+                    "mlp_bwd_half")
+        else:
+            L.check(lib.immoco_mlp_bwd(C.byref(mod.mlp_cfg), L.ptr(enc), 2, 2 * n, n, L.ptr(w1), L.ptr(w2), L.ptr(dout),
+                                       L.ptr(denc), L.ptr(dw1), L.ptr(dw2), st), "mlp_bwd")
         if ctx.plan is not None:
             L.check(lib.immoco_grid_plan_bwd(ctx.plan.handle, L.ptr(denc), L.ptr(dtab), st), "grid_plan_bwd")
         else:
@@ -131,8 +139,10 @@ class _INRFunction(torch.autograd.Function):
 
 class NetworkWithInputEncoding(torch.nn.Module):
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, device="cuda",
-                 lattice_plans=True):
+                 lattice_plans=True, mlp_fp16=False, loss_scale=128.0):
         super().__init__()
+        # mlp_fp16: the network in tcnn's own precision (fp16 operands, fp32 accumulation; tcnn's loss scale)
+        self.mlp_fp16, self.loss_scale = bool(mlp_fp16), float(loss_scale)
         if n_output_dims != 2:
             raise L.ImmocoError("only n_output_dims=2 is supported (the reference's INRs)")
         self.n_input_dims, self.n_output_dims, self.seed = n_input_dims, n_output_dims, seed
@@ -156,18 +166,25 @@ class NetworkWithInputEncoding(torch.nn.Module):
         self.lattice_plans = lattice_plans
         self._plan = None
         self._plan_key = None
+        self._plan_owner = None   # the tensor the key was taken from (kept alive: see _plan_for)
 
     def _split(self, p):
         a, b = self.n_w1, self.n_w1 + self.n_w2
         return p[:a], p[a:b], p[b:]
 
-    def _plan_for(self, x, key):
-        """The cached immoco_grid_plan of input tensor x (identified by `key`), or None when x is not a lattice."""
+    def _plan_for(self, x, key, owner):
+        """The cached immoco_grid_plan of input tensor x (identified by `key`, taken from the caller's tensor
+        `owner`), or None when x is not a lattice.  The key (address, shape, strides, dtype, in-place version) only
+        identifies a tensor while its memory is alive: the caching allocator hands a freed block to the next
+        tensor of the same size, which then has the same key and version 0.  So the cache keeps the keyed tensor
+        (a view of the caller's lattice: the reference passes `identy_grid.view(-1, 2)`, a new view object of the
+        same storage on every call) alive until another input replaces it - its address cannot be reused."""
         if not self.lattice_plans:
             return None
         if key != self._plan_key:
             # (the old plan is freed when the last autograd context that still points at it is gone)
             self._plan, self._plan_key = None, key
+            self._plan_owner = owner
             lat = _detect_lattice(x)
             if lat is not None:
                 try:

@@ -373,6 +373,34 @@ def init_inr_params(geo: GridGeometry, mlp: MLPSpec, seed: int) -> np.ndarray:
     return np.concatenate([w1, w2, tab])
 
 
+class _MLPHalf(torch.autograd.Function):
+    """The bias-free MLP in tiny-cuda-nn's OWN operand precision (reference call sites
+    src/models/immoco.py:11-25,60-65: FullyFusedMLP / CutlassMLP are instantiated with `__half` network
+    precision): every matrix-product operand is rounded to fp16 - the encoding, W1, the hidden activations, W2,
+    and in the backward dL/dout * loss_scale (tcnn's torch binding: loss_scale = 128) and dL/dpre - every
+    product is accumulated in fp32 (tensor cores / MFMA), activations are evaluated in fp32.  Outputs, dL/denc
+    and the weight gradients leave in fp32 (tcnn narrows them to fp16 as well; this mode is never narrower than
+    tcnn).  The derivative of the activation is taken from the STORED fp16 activation, like tcnn's backward."""
+
+    @staticmethod
+    def forward(ctx, enc, w1, w2, act, loss_scale):
+        e16, w1h, w2h = enc.half().float(), w1.half().float(), w2.half().float()
+        pre = e16 @ w1h.t()
+        h16 = (torch.relu(pre) if act == "relu" else torch.tanh(pre)).half().float()
+        ctx.save_for_backward(e16, w1h, w2h, h16)
+        ctx.act, ctx.S = act, float(loss_scale)
+        return h16 @ w2h.t()
+
+    @staticmethod
+    def backward(ctx, dout):
+        e16, w1h, w2h, h16 = ctx.saved_tensors
+        S = ctx.S
+        d16 = (dout * S).half().float()
+        dact = (h16 > 0).float() if ctx.act == "relu" else 1.0 - h16 * h16
+        dp16 = ((d16 @ w2h) * dact).half().float()
+        return (dp16 @ w1h) / S, (dp16.t() @ e16) / S, (d16.t() @ h16) / S, None, None
+
+
 class OracleINR(torch.nn.Module):
     """Stand-in for tinycudann.NetworkWithInputEncoding(n_in, n_out, enc_cfg, net_cfg)
     (call sites immoco.py:60-65,85,93) in fp32 on the CPU.  One flat `params`
@@ -380,9 +408,11 @@ class OracleINR(torch.nn.Module):
     first forward (the reference always passes the same grid)."""
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False,
-                 backend="c", bwd_order=0):
+                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0):
         super().__init__()
         self.table_fp16 = table_fp16   # gather from an fp16 copy of the table (fp32 master, straight-through)
+        self.mlp_fp16 = mlp_fp16       # fp16 MLP operands, fp32 accumulation (_MLPHalf): tcnn's network precision
+        self.loss_scale = loss_scale
         self.backend = backend         # "c": oracle/hashgrid_oracle.c; "torch": the torch expression + autograd
         self.bwd_order = bwd_order     # summation order of the C backward (HashGridPlan)
         self.geo = geometry_from_config(n_input_dims, encoding_config)
@@ -393,6 +423,23 @@ class OracleINR(torch.nn.Module):
         self.params = torch.nn.Parameter(torch.from_numpy(p))
         self._plan: Optional[HashGridPlan] = None
         self._plan_key = None
+        self._row_perm = None          # redraw(): row permutation of the MLP's batch (dW summation order)
+
+    def redraw(self, rng: np.random.Generator):
+        """Draw NEW fp32 summation orders for the next step: the block order of the hash-grid backward
+        (oracle/hashgrid_oracle.c) and the row order of the MLP batch (the order in which dW1 / dW2 sum over the
+        points).  Every order is an equally valid evaluation of the same algorithm - this is what the
+        nondeterministic atomics of tiny-cuda-nn's backward do on EVERY step, where a fixed
+        `bwd_order` keeps one order for a whole trajectory."""
+        self.bwd_order = int(rng.integers(2, 4096))
+        if self._plan is not None:
+            self._plan.bwd_order = self.bwd_order
+            n, blk = self._plan.n_points, 1024
+            if n % blk == 0:
+                bp = torch.from_numpy(rng.permutation(n // blk))
+                self._row_perm = (bp[:, None] * blk + torch.arange(blk)[None, :]).reshape(-1)
+            else:
+                self._row_perm = torch.from_numpy(rng.permutation(n))
 
     def split(self, params=None):
         p = self.params if params is None else params
@@ -414,9 +461,17 @@ class OracleINR(torch.nn.Module):
         if self.table_fp16:
             tab = tab + (tab.half().float() - tab).detach()
         enc = self.plan_for(x).encode(tab, self.backend)
-        pre = enc @ w1.t()
-        h = torch.relu(pre) if self.mlp.activation == "relu" else torch.tanh(pre)
-        out = h @ w2.t()
+        perm = self._row_perm
+        if perm is not None:
+            enc = enc[perm]
+        if self.mlp_fp16:
+            out = _MLPHalf.apply(enc, w1, w2, self.mlp.activation, self.loss_scale)
+        else:
+            pre = enc @ w1.t()
+            h = torch.relu(pre) if self.mlp.activation == "relu" else torch.tanh(pre)
+            out = h @ w2.t()
+        if perm is not None:
+            out = torch.empty_like(out).index_copy(0, perm, out)
         return out[:, : self.n_output_dims]
 
 
@@ -503,6 +558,14 @@ class OracleIMMoCo(torch.nn.Module):
         self.num_movements, self.x, self.num_lines = masks.shape
         self.identy_grid = identity_grid(self.x, self.num_lines)
         self.input_grid = make_grids((self.num_movements, self.x, self.num_lines))
+        self._group_perm = None
+
+    def redraw(self, rng: np.random.Generator):
+        """New summation orders for the next step (see OracleINR.redraw) plus a new order of the motion groups,
+        i.e. of the sum over groups in the backward of `repeat` (immoco.py:91)."""
+        self.image_inr.redraw(rng)
+        self.motion_inr.redraw(rng)
+        self._group_perm = torch.from_numpy(rng.permutation(self.num_movements))
 
     def forward(self):
         H, W, nM = self.x, self.num_lines, self.num_movements
@@ -511,11 +574,14 @@ class OracleIMMoCo(torch.nn.Module):
         images = image_prior.squeeze().unsqueeze(0).repeat(nM, 1, 1)
         grids = self.motion_inr(self.input_grid).float().tanh().view(nM, H, W, 2) \
             + self.identy_grid.view(1, H, W, 2)
+        masks = self.masks
+        if self._group_perm is not None:      # same terms, another order of the group axis
+            grids, masks = grids[self._group_perm], masks[self._group_perm]
         motion_images = torch.view_as_complex(
             F.grid_sample(torch.view_as_real(images).permute(0, 3, 1, 2), grids, mode="bilinear",
                           align_corners=False, padding_mode="zeros").permute(0, 2, 3, 1).contiguous())
-        kspace_out = (FFT(image_prior).squeeze() * (1 - self.masks.sum(0)).float()) + (
-            FFT(motion_images) * self.masks.float()).sum(0)
+        kspace_out = (FFT(image_prior).squeeze() * (1 - masks.sum(0)).float()) + (
+            FFT(motion_images) * masks.float()).sum(0)
         return kspace_out, image_prior
 
 

@@ -3,6 +3,8 @@
 Run on the MI355X box with `pytest -m gpu`."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,6 +168,60 @@ def test_mlp_fwd_bwd(env, which, n):
                                    L.ptr(dw1), L.ptr(dw2), st))
     np.testing.assert_allclose(xl.permute(1, 0, 2).reshape(n, 32).cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dw1.cpu().numpy(), w1.grad.numpy(), rtol=1e-3, atol=1e-4 * s1)
+
+
+@pytest.mark.parametrize("which,n", [("image", 1000), ("motion", 4100), ("motion", 31), ("image", 102400)])
+def test_mlp_half_fwd_bwd_vs_oracle(env, which, n):
+    """tiny-cuda-nn's network precision (immoco_mlp_fwd_half / immoco_mlp_bwd_half: fp16 operands, fp32
+    accumulation on v_mfma_f32_32x32x16_f16, loss scale 128) against the oracle's statement of the same arithmetic
+    (oracle/immoco_oracle.py:_MLPHalf).  The two differ by fp32 summation order and by an occasional 1-ulp flip of
+    a rounded fp16 activation (4.9e-4 of ONE of 64 / 256 hidden values): relative L2 <= 1e-3, worst element <=
+    2e-2 of the largest (a ReLU pre-activation that rounds to +-0 on one side flips act' for that element)."""
+    pkg, L, orc = env
+    net = pkg.network_config if which == "image" else pkg.mot_network_config
+    cfg = L.mlp_cfg(32, 2, net)
+    hid, pad = cfg.n_hidden, cfg.n_out_padded
+    act = "relu" if which == "image" else "tanh"
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, 32, generator=g) * 0.5).requires_grad_(True)
+    w1 = (torch.randn(hid, 32, generator=g) * 0.2).requires_grad_(True)
+    w2 = (torch.randn(pad, hid, generator=g) * 0.2).requires_grad_(True)
+    dout = torch.randn(n, 2, generator=g) * 0.05
+    out = orc._MLPHalf.apply(x, w1, w2, act, 128.0)[:, :2]
+    (out * dout).sum().backward()
+    xd, w1d, w2d, dd = dev(x.detach()), dev(w1.detach()), dev(w2.detach()), dev(dout)
+    st = L.stream_ptr()
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().float(), b.detach().float()
+        rel = float((a - b).norm() / b.norm())
+        worst = float((a - b).abs().max() / b.abs().max())
+        assert rel <= 1e-3 and worst <= 2e-2, (what, rel, worst)
+
+    o = torch.empty(n, 2, device="cuda")
+    L.check(L.lib().immoco_mlp_fwd_half(C.byref(cfg), L.ptr(xd), 32, 2, n, L.ptr(w1d), L.ptr(w2d), L.ptr(o), st))
+    close(o, out, "out")
+    dx = torch.empty(n, 32, device="cuda")
+    dw1 = torch.zeros(hid, 32, device="cuda")
+    dw2 = torch.zeros(pad, hid, device="cuda")
+    L.check(L.lib().immoco_mlp_bwd_half(C.byref(cfg), L.ptr(xd), 32, 2, n, L.ptr(w1d), L.ptr(w2d), L.ptr(dd), 128.0,
+                                        L.ptr(dx), L.ptr(dw1), L.ptr(dw2), st))
+    close(dx, x.grad, "d enc")
+    close(dw1, w1.grad, "dW1")
+    close(dw2[:2], w2.grad[:2], "dW2")
+    assert float(dw2[2:].abs().max()) == 0.0          # padded rows untouched
+    # the exact-fp32 kernels on the same data differ by the fp16 rounding (not bit-identical, not far)
+    o32 = torch.empty(n, 2, device="cuda")
+    L.check(L.lib().immoco_mlp_fwd(C.byref(cfg), L.ptr(xd), 32, 2, n, L.ptr(w1d), L.ptr(w2d), L.ptr(o32), st))
+    d = float((o - o32).norm() / o32.norm())
+    assert 1e-5 < d < 5e-3, d
+    # in-place d-input (din aliases in), level-major strides and a planar dout, as the solver calls it
+    xl = xd.view(n, 16, 2).permute(1, 0, 2).contiguous()
+    dw1.zero_(), dw2.zero_()
+    L.check(L.lib().immoco_mlp_bwd_half(C.byref(cfg), L.ptr(xl), 2, 2 * n, n, L.ptr(w1d), L.ptr(w2d), L.ptr(dd), 128.0,
+                                        L.ptr(xl), L.ptr(dw1), L.ptr(dw2), st))
+    close(xl.permute(1, 0, 2).reshape(n, 32), x.grad, "d enc in place")
+    close(dw1, w1.grad, "dW1 (2)")
 
 
 @pytest.mark.parametrize("which", ["image", "motion"])
@@ -490,11 +546,11 @@ def test_solver_first_steps_vs_oracle(env, golden, use_graph):
     assert e < 0.1, e
 
 
-def _oracle_run_to(orc, ksp, masks, iters_total, K):
+def _oracle_run_to(orc, ksp, masks, iters_total, K, **inr_kw):
     """Oracle loop (immoco.py:164-181) for K iterations, then iteration K itself with everything recorded:
     parameters and Adam state BEFORE it, its loss and gradients, the parameters AFTER its step."""
-    model = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config),
-                             motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config))
+    model = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, **inr_kw),
+                             motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, **inr_kw))
     kin = ksp.div(ksp.abs().max()).mul(16000).clone()
     pm_, pi_ = model.motion_inr.params, model.image_inr.params
     opt = torch.optim.Adam([{"params": [pm_], "lr": 1e-2}, {"params": [pi_], "lr": 1e-2}])
@@ -525,24 +581,25 @@ def _oracle_run_to(orc, ksp, masks, iters_total, K):
     return dict(kin=kin, lam=lam, loss=hist, before=before, grads=grads, after=after, image=ip)
 
 
-def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K):
+def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K, loss_rtol=1e-4, image_tol=1e-4, still_tol=0.0,
+                         **mode):
     """One HIP iteration from the ORACLE's state at iteration K (parameters + Adam moments, step0 = K): no
     chaos can build up, so the late-trajectory arithmetic is compared tightly - loss, the gradient (recovered
     from Adam's first moment: g = (m' - 0.9 m) / 0.1) and the parameter update."""
     from miccai24_immoco_amd.models.immoco import get_solver
     from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
-    o = _oracle_run_to(orc, ksp, masks, iters_total, K)
+    o = _oracle_run_to(orc, ksp, masks, iters_total, K, **mode)
     nM, H, W = masks.shape
-    sol = get_solver(torch.device("cuda", 0), H, W, nM)
+    sol = get_solver(torch.device("cuda", 0), H, W, nM, **mode)
     cg = masks_to_col_group(masks.cuda())
     pi, pm = o["before"]["img"][0].cuda(), o["before"]["mot"][0].cuda()
     ai = torch.cat([o["before"]["img"][1], o["before"]["img"][2]]).cuda()
     am = torch.cat([o["before"]["mot"][1], o["before"]["mot"][2]]).cuda()
     img, _, loss = sol.solve(o["kin"].cuda(), cg, pi, pm, ai, am, 1, 1e-2, o["lam"][K:K + 1], step0=K, want_loss=True)
     rep = {"K": K, "loss_hip": float(loss[0]), "loss_oracle": o["loss"][K], "lambda": o["lam"][K]}
-    assert abs(rep["loss_hip"] - rep["loss_oracle"]) <= 1e-4 * abs(rep["loss_oracle"]), rep
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) <= loss_rtol * abs(rep["loss_oracle"]), rep
     e = float((img.cpu() - o["image"]).abs().max() / o["image"].abs().max())
-    assert e <= 1e-4, e                                    # the forward at the oracle's late-state parameters
+    assert e <= image_tol, e                                    # the forward at the oracle's late-state parameters
     for name, p_new, a_new in (("img", pi, ai), ("mot", pm, am)):
         p0, m0, _ = o["before"][name]
         n = p0.numel()
@@ -551,6 +608,14 @@ def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K):
         gmax = float(g_ref.abs().max())
         rel_l2 = float((g_hip - g_ref).norm() / g_ref.norm())
         max_abs = float((g_hip - g_ref).abs().max()) / gmax
+        if os.environ.get("IMMOCO_TF_DIAG"):
+            dd = (g_hip - g_ref).abs()
+            top = torch.topk(dd, 8)
+            nw = sol.n_params_image - 2 * 5592320 if name == "img" else sol.n_params_motion - 2 * 7114752
+            print("diag", name, "n_weights", nw, "top err idx", top.indices.tolist(), "err", top.values.tolist(),
+                  "ref", g_ref[top.indices].tolist(), "hip", g_hip[top.indices].tolist(),
+                  "rel L2 weights", float((g_hip[:nw] - g_ref[:nw]).norm() / g_ref[:nw].norm()),
+                  "rel L2 table", float((g_hip[nw:] - g_ref[nw:]).norm() / g_ref[nw:].norm()))
         upd_h, upd_o = p_new.cpu() - p0, o["after"][name] - p0
         d = (upd_h - upd_o).abs()
         moved = upd_o.abs() > 0
@@ -570,7 +635,7 @@ def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K):
     print("teacher-forced", rep)
     for name in ("img", "mot"):
         assert rep[name]["untouched_moved_by_hip"] == 0, (name, rep[name])
-        assert rep[name]["max_oracle_step_where_hip_is_still"] <= 0.0, (name, rep[name])   # nothing beyond rounding
+        assert rep[name]["max_oracle_step_where_hip_is_still"] <= still_tol, (name, rep[name])   # nothing beyond rounding
     return rep
 
 
@@ -593,6 +658,28 @@ def test_teacher_forced_late_state_96(env, K):
         assert r["grad_rel_l2"] <= 1e-4 and r["grad_max_abs_over_max"] <= 1e-4, (name, r)
         assert r["upd_max"] <= 1e-3 * 1e-2 and r["frac_update_off_by_1e3_lr"] == 0.0, (name, r)
         assert r["upd_rel_l2"] <= 1e-3, (name, r)
+
+
+@pytest.mark.parametrize("K", [60, 130])
+@pytest.mark.parametrize("table_fp16", [False, True])
+def test_teacher_forced_mlp_fp16_96(env, K, table_fp16):
+    """The same in tiny-cuda-nn's network precision (cfg.mlp_fp16: fp16 MLP operands, fp32 accumulation, loss
+    scale 128; with table_fp16 also fp16 feature tables = "tcnn's own arithmetic", immoco.py:11-25,60-65) against
+    the oracle in that mode (OracleINR(mlp_fp16=True)): loss rtol 1e-3, gradients relative L2 <= 5e-3 at K = 60.
+    At K = 130 the motion gradient is a small residual of cancelling per-point terms, and HIP's tanh (3e-6 relative)
+    rounds 0.03 % of the hidden activations to the neighbouring fp16 value: replacing torch.tanh by that formula in
+    the ORACLE ALONE moves its motion gradient by 6e-4 ... 5e-3 relative L2 there (tools note in DESIGN.md 2.3), so
+    the bound at K = 130 is 2e-2; measured 1.2e-4 / 5.5e-3 (fp16 / fp32 tables), image gradients <= 3e-5."""
+    pkg, L, orc = env
+    from oracle import synth_cpu
+    s = synth_cpu.make_slice(96, 96, 3, 11)
+    masks = orc.extract_movement_groups(s["lines"], make_list=True)
+    rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 200, K, loss_rtol=1e-3, image_tol=5e-3, still_tol=1e-5,
+                               mlp_fp16=True, table_fp16=table_fp16)
+    assert rep["img"]["grad_rel_l2"] <= 5e-3, rep["img"]
+    assert rep["mot"]["grad_rel_l2"] <= (5e-3 if K == 60 else 2e-2), rep["mot"]
+    for name in ("img", "mot"):
+        assert rep[name]["upd_rel_l2"] <= 5e-2, (name, rep[name])
 
 
 def test_teacher_forced_lambda_zero_phase_96(env):
@@ -1060,6 +1147,50 @@ def test_solver_config5_shape_and_precision_vs_oracle_record(env, golden):
     # fp16 features: close to, not equal to, fp32 (the FIRST losses can coincide after rounding to fp32: the initial
     # tables are +-1e-4, their fp16 rounding error is below the loss's ulp)
     assert abs(a[0] - lf[0]) <= 1e-2 * a[0] and not np.array_equal(a[:5].astype(np.float64), lf[:5])
+
+
+@pytest.mark.parametrize("shape", [(24, 320, 320), (21, 320, 320), (12, 512, 512)])
+def test_solver_multi_round_plans_vs_atomic_scatter(env, shape):
+    """lattices over 2 M points run the motion grid's transposed index in several ROUNDS
+    (launches of 8 point ranges into the same 8 partial tables).  Which item overwrites a (table, slot block) and
+    which one adds to it is decided per item at plan build: at these shapes 8 ... 120 blocks of the wrapped-stride
+    levels 12-15 have their only, non-shared item in a later round (round 2's code decided per round and such a
+    block kept accumulating stale gradients for ever; 20x640x640, the only multi-round shape tested then, hides
+    it because every such block is flushed with atomics and cleared by Adam there).
+    Teacher-forced so that no chaos builds up: the plan solver runs two iterations (anything stale would now sit in
+    its gradient tiles), then ONE more iteration from that state with the plan solver and with the generic atomic
+    scatter: Adam's first moments (0.9 m + 0.1 g_3) agree to summation accuracy; a stale block would carry
+    g_3 + g_2 + g_1 instead of g_3."""
+    pkg, L, orc = env
+    from miccai24_immoco_amd.models.immoco import get_solver, _SOLVERS
+    nM, H, W = shape
+    g = torch.Generator().manual_seed(nM * 1000 + H)
+    ksp = (torch.randn(H, W, generator=g) + 1j * torch.randn(H, W, generator=g)).to(torch.complex64).cuda()
+    kin = ksp / ksp.abs().max() * 16000
+    cg = torch.randint(0, nM + 1, (W,), generator=g, dtype=torch.int32).cuda()
+    sol = get_solver("cuda", H, W, nM)
+    pi, pm = sol.init_params()
+    ai, am = torch.zeros(2 * pi.numel(), device="cuda"), torch.zeros(2 * pm.numel(), device="cuda")
+    sol.solve(kin, cg, pi, pm, ai, am, 2, 1e-2, [1e-2] * 2)
+    state = [t.clone() for t in (pi, pm, ai, am)]
+    _, _, l_plan = sol.solve(kin, cg, pi, pm, ai, am, 1, 1e-2, [1e-2], step0=2, want_loss=True)
+    m_plan = (am[:pm.numel()].cpu(), ai[:pi.numel()].cpu())
+    for k in [k for k in _SOLVERS if k[1:4] == (H, W, nM)]:
+        _SOLVERS.pop(k).close()
+    torch.cuda.empty_cache()
+    sol = get_solver("cuda", H, W, nM, atomic_scatter=True)
+    pi, pm, ai, am = state
+    _, _, l_at = sol.solve(kin, cg, pi, pm, ai, am, 1, 1e-2, [1e-2], step0=2, want_loss=True)
+    m_at = (am[:pm.numel()].cpu(), ai[:pi.numel()].cpu())
+    for k in [k for k in _SOLVERS if k[1:4] == (H, W, nM)]:
+        _SOLVERS.pop(k).close()
+    torch.cuda.empty_cache()
+    np.testing.assert_allclose(l_plan.cpu().numpy(), l_at.cpu().numpy(), rtol=1e-5)
+    for a, b, nm in ((m_plan[0], m_at[0], "motion"), (m_plan[1], m_at[1], "image")):
+        rel = float((a - b).norm() / b.norm())
+        worst = float((a - b).abs().max() / b.abs().max())
+        print(shape, nm, "first-moment rel L2", rel, "max/max", worst)
+        assert rel <= 1e-4 and worst <= 1e-3, (shape, nm, rel, worst)
 
 
 def test_batch_of_slices_independent(env):
