@@ -109,6 +109,12 @@ def main():
     ap.add_argument("--grad-parts", type=int, default=0, help="transposed-index parts (0 = library default)")
     ap.add_argument("--table-fp16", action="store_true",
                     help="fp16 hash-grid features (BASELINE config 5 precision); default fp32 like config 2")
+    ap.add_argument("--mlp-fp16", action="store_true",
+                    help="both MLPs with fp16 operands / fp32 accumulation (tiny-cuda-nn's network precision); "
+                         "default exact fp32")
+    ap.add_argument("--chains", choices=["auto", "fork", "serial"], default="auto",
+                    help="image / motion kernel chains as two graph branches (fork), one after the other (serial), or "
+                         "decided by the lattice size (auto, the library default)")
     ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
                     help="c2 (default, the metric's configuration): 320x320, 10 groups; c3: batches of --batch such "
                          "slices on one GPU; c5 (informational): 640x640, 20 groups, implies --table-fp16")
@@ -162,12 +168,17 @@ def main():
     nM = int(slices[0]["masks"].shape[0])
     if any(int(sl["masks"].shape[0]) != nM for sl in slices) and args.workload == "c3":
         raise SystemExit("synthetic slices ended up with different group counts")
-    get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16)      # plans + workspace (one-off, like FFT plan creation)
+    def the_solver(lanes=0, grad_parts=None):
+        return get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts if grad_parts is None else grad_parts,
+                          0, args.table_fp16, lanes, mlp_fp16=args.mlp_fp16,
+                          serial_chains={"auto": None, "fork": False, "serial": True}[args.chains])
+    the_solver()      # plans + workspace (one-off, like FFT plan creation)
 
     def solve(sl):
         return pkg.imcoco_motion_correction(sl["kspace"], sl["masks"], iters=args.iters, learning_rate=1e-2,
                                             lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts,
-                                            table_fp16=args.table_fp16)
+                                            table_fp16=args.table_fp16, mlp_fp16=args.mlp_fp16,
+                                            serial_chains={"auto": None, "fork": False, "serial": True}[args.chains])
 
     def step(j):
         """One step = one pass of the hot path over one batch: a slice (c2, c5) or B slices (c3)."""
@@ -175,7 +186,8 @@ def main():
             return [solve(slices[j])[0]]
         grp = slices[j * B:(j + 1) * B]
         imgs, _ = pkg.imcoco_motion_correction_batch(torch.stack([g["kspace"] for g in grp]), [g["masks"] for g in grp],
-                                                     iters=args.iters, lanes=args.lanes, table_fp16=args.table_fp16)
+                                                     iters=args.iters, lanes=args.lanes, table_fp16=args.table_fp16,
+                                                     mlp_fp16=args.mlp_fp16)
         return list(imgs)
 
     def barrier():
@@ -198,8 +210,7 @@ def main():
         dt = float(t.item())
     value = K * B * world / dt
     ms_per_step = dt / K * 1e3
-    graph_used = bool(get_solver(dev, H, W, nM, not args.no_graph, False, 0 if B > 1 else args.grad_parts, 0,
-                                 args.table_fp16, args.lanes if B > 1 else 0).graph_active)   # of the timed solves
+    graph_used = bool(the_solver(args.lanes if B > 1 else 0, 0 if B > 1 else None).graph_active)   # of the timed solves
 
     out = None
     if rank == 0:
@@ -222,7 +233,7 @@ def main():
                                   "deviation of 1.75 dB once lambda_GE has underflowed to 0 at iteration 1500 (64 runs: mean "
                                   "34.96 dB vs the six oracle records' 34.62, profiles/r02_c2_end_psnr_{24,40}runs.txt; DESIGN.md 2)"}
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
-        solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16)
+        solver = the_solver()
         sl = slices[0]
         k = sl["kspace"]
         kin = k / k.abs().max() * 16000
@@ -304,7 +315,10 @@ def main():
             else "slices/sec at 640x640, 20 motion groups (BASELINE config 5; informational)",
             "value": round(value, 5), "unit": "slices/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32+f16tab" if args.table_fp16 else "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {(False, False): "f32", (True, False): "f32+f16tab", (False, True): "f16mlp/f32acc",
+                      (True, True): "f16mlp+f16tab/f32acc"}[(bool(args.table_fp16), bool(args.mlp_fp16))],
+            "data": "synthetic",
             "config": {"workload": {"c2": "C2: single 320x320 slice, 10 motion groups, 3000 Adam iters, hash-grid INRs",
                                     "c3": f"C3: batch of {B} independent 320x320 slices on one GPU, {args.lanes} in flight",
                                     "c5": "C5: single 640x640 slice, 20 motion groups, fp16 hash-grid features + fp32 Adam"

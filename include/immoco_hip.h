@@ -229,8 +229,9 @@ typedef struct immoco_solver_cfg {
                              0 = chosen from the lattice size so that one level slice of dL/denc per
                              part is ~2 MB, the share of an XCD's L2: 4 at 320x320x10, 32 at 640x640x20);
                              up to 8 parts run in one launch, each into its own partial gradient table */
-  int32_t serial_chains;  /* 1: run the image-INR and motion-INR kernel chains one after the other
-                             (default 0: two concurrent branches of the graph) */
+  int32_t serial_chains;  /* 1: run the image-INR and motion-INR kernel chains one after the other; 0: two
+                             concurrent branches of the graph; 2: the library decides (the fork: it measures faster
+                             at 320x320x10 and at 640x640x20) */
   int32_t table_fp16;     /* 1: gather the hash-grid features from fp16 shadows of the tables (what
                              tiny-cuda-nn does; BASELINE config 5), fp32 master tables + fp32 Adam;
                              default 0: everything fp32 */

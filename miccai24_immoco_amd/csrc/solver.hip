@@ -182,6 +182,17 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   return launch_image_grad_init(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
                                                 b.loss_hist, s->dimage, q);
                 }});
+  // Where the second fork sits.  "late" (exact-fp32 MLPs): after the motion MLP backward - the wide MLP backward
+  // needs 448 registers and 105 KB of LDS there and cannot share a CU with anything, so it runs beside the
+  // gather-bound encode backward (and starves: DESIGN.md 4.4).  "early" (fp16 MLPs): right after the warp backward -
+  // the two MLP backwards (62 + 2 x 34 KB of LDS, <= 256 registers) share the CUs, the image chain's small encode
+  // backward and Adam then start beside the motion grid's encode backward instead of queueing behind its 6000
+  // workgroups.  A/B switch (environment, read once): IMMOCO_FORK=early|late.
+  static const int fork_env = [] {
+    const char* e = getenv("IMMOCO_FORK");
+    return !e ? -1 : (strcmp(e, "early") == 0 ? 1 : 0);
+  }();
+  const bool fork_early = fork_env >= 0 ? fork_env == 1 : s->cfg.mlp_fp16 != 0;
   if (nM > 0) {
     st.push_back({"motion_warp_bwd", [=](hipStream_t q) {
                     return launch_motion_warp_bwd(s->image, s->t_mot, s->xs, s->ys, slot1, nM, H, W, s->dimage,
@@ -193,8 +204,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                                 s->enc_mot, g_w1m, g_w2m, q, 0, TCNN_LOSS_SCALE);
                     return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
                                           s->enc_mot, g_w1m, g_w2m, q);
-                  }});  // before the fork: the image chain's MFMA-bound MLP backward then runs beside the
-                        // gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
+                  }, fork_early ? 1 : 0});  // "late": before the fork, the image chain's MFMA-bound MLP backward
+                        // then runs beside the gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
   }
   if (nM > 0) {
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
@@ -444,6 +455,11 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   if ((rc = check_mlp_cfg(&cfg->image_mlp)) || (rc = check_mlp_cfg(&cfg->motion_mlp))) return rc;
   immoco_solver* s = new immoco_solver();
   s->cfg = *cfg;
+  // serial_chains = 2: the library decides.  Measured on MI355X (bench.py --workload c5 --chains fork|serial, 300 and
+  // 600 iterations, round 3): 640x640x20 forked 8.00 ms per iteration, serial 8.19, sum of the isolated kernels 8.23;
+  // 320x320x10 forked 1.25, serial 1.40.  The fork wins at both ends, so "auto" is the fork (round 2's 9.09 ms at C5
+  // was the 27 s solve's sustained clock, not the fork: DESIGN.md 4.4).
+  if (s->cfg.serial_chains == 2) s->cfg.serial_chains = 0;
   if ((rc = build_levels(&cfg->image_grid, &s->lv_img)) || (rc = build_levels(&cfg->motion_grid, &s->lv_mot))) {
     delete s;
     return rc;
@@ -640,36 +656,51 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
   const std::vector<Step> first = arrange(all, pipelined ? Order::First : Order::Classic);
   const std::vector<Step> steady = pipelined ? arrange(all, Order::Steady) : first;
   auto run_list = [&](const std::vector<Step>& l) { return s->cfg.serial_chains ? run_steps(l, q) : run_steps_forked(s, l, q); };
-  auto capture = [&](const std::vector<Step>& l, hipGraphExec_t* out) {
+  auto capture = [&](const std::vector<Step>& l, hipGraphExec_t* out, int reps) {
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal) != hipSuccess) return;
-    const int r = run_list(l);
+    int r = IMMOCO_OK;
+    for (int k = 0; k < reps && r == IMMOCO_OK; ++k) r = run_list(l);
     const hipError_t e2 = hipStreamEndCapture(q, &graph);
     if (r == IMMOCO_OK && e2 == hipSuccess && graph)
       if (hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
     if (graph) hipGraphDestroy(graph);
   };
+  // K iterations per graph launch (everything iteration-dependent is read through the device-side counter, so a
+  // graph of K iterations is K copies of the same nodes): removes K - 1 of every K graph launches with their
+  // root-fork delay and end-of-graph gap (rocprofv3 timeline: ~12 + 10 us of 1250).  The remainder runs on the
+  // single-iteration graph.  A/B switch (environment, read once): IMMOCO_GRAPH_K (default 8; 1 = one per launch).
+  static const int graph_k = [] { const char* e = getenv("IMMOCO_GRAPH_K"); const int k = e ? atoi(e) : 8; return k < 1 ? 1 : (k > 64 ? 64 : k); }();
+  const int GK = pipelined ? 1 : graph_k;
   s->graph_active = 0;
   if (s->cfg.use_graph) {
     std::vector<const void*> key = {kspace_in,  col_group,   params_image, params_motion,
                                     adam_image, adam_motion, loss_hist,    s->sched, pipelined ? s : nullptr};
     sweep_retired(s, false);
-    if (!s->gexec || key != s->gkey || (pipelined && iters > 1 && !s->gexec2)) {
+    const bool want_k = !pipelined && GK > 1 && iters >= GK;
+    if (!s->gexec || key != s->gkey || (pipelined && iters > 1 && !s->gexec2) || (want_k && !s->gexec2)) {
       retire_graph(s);
-      capture(first, &s->gexec);
-      if (pipelined && iters > 1 && s->gexec) capture(steady, &s->gexec2);
+      capture(first, &s->gexec, 1);
+      if (pipelined && iters > 1 && s->gexec) capture(steady, &s->gexec2, 1);
+      if (want_k && s->gexec) capture(first, &s->gexec2, GK);   // classic order: gexec2 = GK iterations
       (void)hipGetLastError();
       s->gkey = key;
     }
     s->graph_active = s->gexec != nullptr && (!pipelined || iters == 1 || s->gexec2 != nullptr);
   }
-  for (int j = 0; j < iters; ++j) {
+  for (int j = 0; j < iters;) {
     const bool st = pipelined && j > 0;
     if (s->graph_active) {
+      if (!pipelined && s->gexec2 && GK > 1 && iters - j >= GK) {
+        IMMOCO_CHECK_HIP(hipGraphLaunch(s->gexec2, q));
+        j += GK;
+        continue;
+      }
       IMMOCO_CHECK_HIP(hipGraphLaunch(st ? s->gexec2 : s->gexec, q));
     } else if ((rc = run_list(st ? steady : first))) {
       return rc;
     }
+    ++j;
   }
   if (pipelined && (rc = run_steps_forked(s, arrange(all, Order::Epilogue), q))) return rc;   // Adam steps of the last iteration
   // tensors of the LAST forward pass (immoco.py:203-206)

@@ -147,7 +147,7 @@ class _SolverHandle:
     """RAII wrapper of immoco_solver_t; cached per (device, H, W, nM)."""
 
     def __init__(self, device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, table_fp16=False,
-                 batch_lanes=0, mlp_fp16=False, serial_chains=False):
+                 batch_lanes=0, mlp_fp16=False, serial_chains=None):
         self.device, self.H, self.W, self.nM = device, H, W, nM
         self.image_grid = L.grid_cfg(2, encoding_config)
         self.motion_grid = L.grid_cfg(3, encoding_config)
@@ -155,7 +155,7 @@ class _SolverHandle:
         self.motion_mlp = L.mlp_cfg(32, 2, mot_network_config)
         cfg = L.SolverCfg(H, W, nM, self.image_grid, self.motion_grid, self.image_mlp, self.motion_mlp,
                           1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts),
-                          1 if serial_chains else 0, 1 if table_fp16 else 0, int(batch_lanes), 1 if mlp_fp16 else 0)
+                          2 if serial_chains is None else (1 if serial_chains else 0), 1 if table_fp16 else 0, int(batch_lanes), 1 if mlp_fp16 else 0)
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(L.lib().immoco_solver_create(C.byref(cfg), C.byref(self.handle)), "solver_create")
@@ -261,12 +261,12 @@ _SOLVERS = {}
 
 
 def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, instance=0,
-               table_fp16=False, batch_lanes=0, mlp_fp16=False, serial_chains=False) -> _SolverHandle:
+               table_fp16=False, batch_lanes=0, mlp_fp16=False, serial_chains=None) -> _SolverHandle:
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance),
-           bool(table_fp16), int(batch_lanes), bool(mlp_fp16), bool(serial_chains))
+           bool(table_fp16), int(batch_lanes), bool(mlp_fp16), serial_chains)
     s = _SOLVERS.get(key)
     if s is None:
         s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts, table_fp16,
@@ -295,7 +295,7 @@ def lambda_schedule(iters, lambda_ge, rule="immoco"):
 def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2, debug=False,
                              *, seed=1337, norm_scale=16000.0, lambda_rule="immoco", return_loss=False,
                              use_graph=True, atomic_scatter=False, grad_parts=0, instance=0, table_fp16=False,
-                             mlp_fp16=False):
+                             mlp_fp16=False, serial_chains=None):
     """IM-MoCo per-slice solve (immoco.py:116-206).
 
     Args mirror the reference: ``kspace_corr`` [H, W] complex (any device), ``masks`` [nM, H, W]
@@ -315,7 +315,7 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
     nM, H, W = masks.shape
     lambdas = lambda_schedule(iters, lambda_ge, lambda_rule)   # raises ZeroDivisionError like the reference
     solver = get_solver(dev, H, W, nM, use_graph, atomic_scatter, grad_parts, instance, table_fp16,
-                        mlp_fp16=mlp_fp16)
+                        mlp_fp16=mlp_fp16, serial_chains=serial_chains)
     k = kspace_corr.to(dev).to(torch.complex64).contiguous()
     if k.shape != (H, W):
         raise L.ImmocoError(f"kspace_corr shape {tuple(k.shape)} does not match masks {(H, W)}")
