@@ -120,6 +120,7 @@ def main():
                          "slices on one GPU; c5 (informational): 640x640, 20 groups, implies --table-fp16")
     ap.add_argument("--batch", type=int, default=64, help="slices per batch (c3)")
     ap.add_argument("--lanes", type=int, default=1, help="slices in flight side by side (c3; 1 is fastest)")
+    ap.add_argument("--pair", action="store_true", help="c3: two slices per graph, gathers serialised (batch_pair)")
     args = ap.parse_args()
     global H, W, N_MOVEMENTS
     if args.workload == "c5":
@@ -171,7 +172,8 @@ def main():
     def the_solver(lanes=0, grad_parts=None):
         return get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts if grad_parts is None else grad_parts,
                           0, args.table_fp16, lanes, mlp_fp16=args.mlp_fp16,
-                          serial_chains={"auto": None, "fork": False, "serial": True}[args.chains])
+                          serial_chains={"auto": None, "fork": False, "serial": True}[args.chains],
+                          batch_pair=bool(args.pair) and B > 1)
     the_solver()      # plans + workspace (one-off, like FFT plan creation)
 
     def solve(sl):
@@ -187,7 +189,7 @@ def main():
         grp = slices[j * B:(j + 1) * B]
         imgs, _ = pkg.imcoco_motion_correction_batch(torch.stack([g["kspace"] for g in grp]), [g["masks"] for g in grp],
                                                      iters=args.iters, lanes=args.lanes, table_fp16=args.table_fp16,
-                                                     mlp_fp16=args.mlp_fp16)
+                                                     mlp_fp16=args.mlp_fp16, pair=args.pair)
         return list(imgs)
 
     def barrier():

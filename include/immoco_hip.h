@@ -244,7 +244,10 @@ typedef struct immoco_solver_cfg {
   int32_t mlp_fp16;       /* 1: both MLPs in tiny-cuda-nn's network precision (immoco_mlp_fwd_half / _bwd_half: fp16
                              operands, fp32 accumulation, loss scale 128); with table_fp16 this is "tcnn's own
                              arithmetic" (immoco.py:11-25,60-65).  default 0: exact fp32 on the f32 MFMA */
-  int32_t reserved[1];
+  int32_t batch_pair;     /* immoco_solver_solve_batch: 1 = slices are solved two at a time inside ONE captured graph whose
+                             four hash-grid gather kernels (motion encode forward / backward of either slice) are
+                             chained by events so that never two of them run at once, while the rest of one slice
+                             (MLPs, warp, FFTs, losses, Adam, image chain) runs beside the other slice's gather */
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;

@@ -45,7 +45,7 @@ class SolverCfg(C.Structure):
                 ("image_mlp", MlpCfg), ("motion_mlp", MlpCfg),
                 ("use_graph", C.c_int32), ("atomic_scatter", C.c_int32), ("grad_parts", C.c_int32),
                 ("serial_chains", C.c_int32), ("table_fp16", C.c_int32),
-                ("batch_lanes", C.c_int32), ("mlp_fp16", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("batch_lanes", C.c_int32), ("mlp_fp16", C.c_int32), ("batch_pair", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32

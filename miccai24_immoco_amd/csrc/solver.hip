@@ -73,6 +73,10 @@ struct immoco_solver {
   // phase timing of the last profile call
   std::vector<std::string> phase_names;
   std::vector<float> phase_ms;
+  // paired batch mode (cfg.batch_pair): events that order the two slices' gather kernels, the pair's graphs
+  hipEvent_t ev_pair[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t pg1 = nullptr, pgk = nullptr;   // one / GK double-iterations
+  std::vector<const void*> pkey;
   // batch lanes (immoco_solver_solve_batch): further workspaces that share this solver's lattices and plans
   immoco_solver* parent = nullptr;
   std::vector<immoco_solver*> lanes;
@@ -343,7 +347,7 @@ std::vector<Step> arrange(const std::vector<Step>& all, Order o) {
 // host is that far ahead of the GPU only in batch solves), and when the solver is destroyed or re-planned.
 constexpr size_t RETIRED_MAX = 16;
 void retire_graph(immoco_solver* s) {
-  for (hipGraphExec_t* g : {&s->gexec, &s->gexec2}) {
+  for (hipGraphExec_t* g : {&s->gexec, &s->gexec2, &s->pg1, &s->pgk}) {
     if (!*g) continue;
     s->retired.emplace_back(*g, nullptr);
     *g = nullptr;
@@ -369,7 +373,9 @@ int run_steps(const std::vector<Step>& steps, hipStream_t q) {
 }
 
 // fork/join execution of the branch annotations (works eagerly and under stream capture)
-int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q);
+// hook(step, stream, before): called right before / after a step is issued on its stream (cross-slice ordering)
+typedef std::function<int(const Step&, hipStream_t, bool)> StepHook;
+int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q, const StepHook* hook = nullptr);
 
 int ensure_sched(immoco_solver* s, int32_t iters) {
   if (iters <= s->sched_cap) return IMMOCO_OK;
@@ -409,7 +415,7 @@ int leave(immoco_solver* s, hipStream_t caller) {
 }  // namespace
 
 namespace {
-int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q) {
+int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q, const StepHook* hook) {
   bool forked = false;
   int ev = 0;
   for (const Step& st : steps) {
@@ -427,8 +433,11 @@ int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream
     hipStream_t sq = st.branch == 2 ? s->side : q;
     const bool mark = strcmp(st.name, "motion_encode_bwd") == 0;
     if (mark) IMMOCO_CHECK_HIP(hipEventRecord(s->ev_k0, sq));
-    int rc = st.run(sq);
+    int rc;
+    if (hook && (rc = (*hook)(st, sq, true))) return rc;
+    rc = st.run(sq);
     if (rc) return rc;
+    if (hook && (rc = (*hook)(st, sq, false))) return rc;
     if (mark) {
       IMMOCO_CHECK_HIP(hipEventRecord(s->ev_k1, sq));
       s->marked = true;
@@ -557,6 +566,8 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
     if (ev) hipEventDestroy(ev);
   if (s->ev_k0) hipEventDestroy(s->ev_k0);
   if (s->ev_k1) hipEventDestroy(s->ev_k1);
+  for (hipEvent_t ev : s->ev_pair)
+    if (ev) hipEventDestroy(ev);
   if (s->side) hipStreamDestroy(s->side);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
@@ -609,45 +620,79 @@ extern "C" int immoco_solver_set_lattice(immoco_solver_t s, const float* xs, con
 }
 
 namespace {
+struct SliceArgs {
+  const float* kin;
+  const int32_t* cg;
+  float *pi, *pm, *ai, *am;
+  float *out_image, *out_kspace, *loss;
+};
+
+int check_slice(immoco_solver* s, const SliceArgs& a, int32_t iters, const float* lambda_sched, int32_t step0) {
+  IMMOCO_REQUIRE(s, "solver_solve: NULL solver");
+  IMMOCO_REQUIRE(s->lattice_set, "solver_solve: call immoco_solver_set_lattice first");
+  IMMOCO_REQUIRE(a.kin && a.cg && a.pi && a.ai, "solver_solve: NULL buffer");
+  IMMOCO_REQUIRE(s->cfg.nM == 0 || (a.pm && a.am), "solver_solve: NULL motion buffer");
+  IMMOCO_REQUIRE(iters >= 1 && lambda_sched && step0 >= 0, "solver_solve: bad iters/schedule");
+  return IMMOCO_OK;
+}
+
+// Per-solve initialisation of workspace `w` on stream q: schedules on the device, iteration counter, loss
+// history, fp16 shadows, transposed measured k-space.
+int prepare_slice(immoco_solver* w, hipStream_t q, const SliceArgs& a, int32_t iters, float lr,
+                  const float* lambda_sched, int32_t step0) {
+  int rc;
+  if ((rc = ensure_sched(w, iters))) return rc;
+  // host-side scalars in double like python/torch (immoco.py:180-181; torch Adam bias corrections)
+  std::vector<float> both(3 * (size_t)iters);
+  for (int j = 0; j < iters; ++j) {
+    const double t = (double)(step0 + j + 1);
+    both[2 * j] = (float)((double)lr / (1.0 - pow(0.9, t)));
+    both[2 * j + 1] = (float)sqrt(1.0 - pow(0.999, t));
+    both[2 * (size_t)iters + j] = lambda_sched[j];
+  }
+  // the schedules only change with (iters, lr, step0, lambda): a batch re-uses them slice after slice, and
+  // skipping the upload also skips the host sync it needs (the lane would drain before the next slice is queued)
+  if (both != w->sched_host) {
+    IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // nothing in flight may still read the old schedules
+    IMMOCO_CHECK_HIP(hipMemcpyAsync(w->sched, both.data(), (size_t)iters * 8, hipMemcpyHostToDevice, q));
+    IMMOCO_CHECK_HIP(hipMemcpyAsync(w->lambda_dev, both.data() + 2 * (size_t)iters, (size_t)iters * 4, hipMemcpyHostToDevice, q));
+    IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vector goes out of scope; also orders the pageable copies
+    w->sched_host.swap(both);
+  }
+  IMMOCO_CHECK_HIP(hipMemsetAsync(w->iter_dev, 0, 4 * sizeof(int32_t), q));
+  if (a.loss) IMMOCO_CHECK_HIP(hipMemsetAsync(a.loss, 0, (size_t)iters * 4, q));
+  if ((rc = refresh_shadows(w, a.pi, a.pm, q))) return rc;
+  return launch_transpose_c64(a.kin, w->kin_t, w->cfg.H, w->cfg.W, q);
+}
+
+// tensors of the LAST forward pass (immoco.py:203-206)
+int finish_slice(immoco_solver* w, hipStream_t q, const SliceArgs& a) {
+  if (a.out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(a.out_image, w->image, (size_t)w->P * 8, hipMemcpyDeviceToDevice, q));
+  if (a.out_kspace) return launch_transpose_c64(w->kout, a.out_kspace, w->cfg.W, w->cfg.H, q);
+  return IMMOCO_OK;
+}
+
+// K iterations per graph launch (everything iteration-dependent is read through the device-side counter, so a
+// graph of K iterations is K copies of the same nodes): removes K - 1 of every K graph launches with their
+// root-fork delay and end-of-graph gap.  Measured at 320x320x10: 1.2513 -> 1.2495 ms per iteration (the gaps hide
+// behind the device-side queue).  A/B switch (environment, read once): IMMOCO_GRAPH_K (default 8; 1 = one per launch).
+int graph_k() {
+  static const int k = [] { const char* e = getenv("IMMOCO_GRAPH_K"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  return k;
+}
+
 // sync_in / sync_out: order the solve after / the caller's stream after it (a batch does this once per lane)
 int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_group, float* params_image,
                float* params_motion, float* adam_image, float* adam_motion, int32_t iters, float lr,
                const float* lambda_sched, int32_t step0, float* out_image, float* out_kspace, float* loss_hist,
                void* stream, bool sync_in, bool sync_out) {
-  IMMOCO_REQUIRE(s, "solver_solve: NULL solver");
-  IMMOCO_REQUIRE(s->lattice_set, "solver_solve: call immoco_solver_set_lattice first");
-  IMMOCO_REQUIRE(kspace_in && col_group && params_image && adam_image, "solver_solve: NULL buffer");
-  IMMOCO_REQUIRE(s->cfg.nM == 0 || (params_motion && adam_motion), "solver_solve: NULL motion buffer");
-  IMMOCO_REQUIRE(iters >= 1 && lambda_sched && step0 >= 0, "solver_solve: bad iters/schedule");
-  hipStream_t caller = as_stream(stream);
+  const SliceArgs a{kspace_in, col_group, params_image, params_motion, adam_image, adam_motion, out_image, out_kspace, loss_hist};
   int rc;
-  if ((rc = ensure_sched(s, iters))) return rc;
-  // host-side scalars in double like python/torch (immoco.py:180-181; torch Adam bias corrections)
-  std::vector<float> sched(2 * (size_t)iters), lam((size_t)iters);
-  for (int j = 0; j < iters; ++j) {
-    const double t = (double)(step0 + j + 1);
-    sched[2 * j] = (float)((double)lr / (1.0 - pow(0.9, t)));
-    sched[2 * j + 1] = (float)sqrt(1.0 - pow(0.999, t));
-    lam[j] = lambda_sched[j];
-  }
+  if ((rc = check_slice(s, a, iters, lambda_sched, step0))) return rc;
+  hipStream_t caller = as_stream(stream);
   if (sync_in && (rc = enter(s, caller))) return rc;
   hipStream_t q = s->stream;
-  // the schedules only change with (iters, lr, step0, lambda): a batch re-uses them slice after slice, and
-  // skipping the upload also skips the host sync it needs (the lane would drain before the next slice is queued)
-  std::vector<float> both(sched);
-  both.insert(both.end(), lam.begin(), lam.end());
-  if (both != s->sched_host) {
-    IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // nothing in flight may still read the old schedules
-    IMMOCO_CHECK_HIP(hipMemcpyAsync(s->sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, q));
-    IMMOCO_CHECK_HIP(hipMemcpyAsync(s->lambda_dev, lam.data(), lam.size() * 4, hipMemcpyHostToDevice, q));
-    IMMOCO_CHECK_HIP(hipStreamSynchronize(q));  // host vectors go out of scope; also orders the pageable copies
-    s->sched_host.swap(both);
-  }
-  IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
-  if (loss_hist) IMMOCO_CHECK_HIP(hipMemsetAsync(loss_hist, 0, (size_t)iters * 4, q));
-
-  if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
-  if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
+  if ((rc = prepare_slice(s, q, a, iters, lr, lambda_sched, step0))) return rc;
   Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
   // rotated order (see arrange()): an A/B switch (IMMOCO_PIPELINE=1), OFF by default - measured slower
   static const bool want_pipeline = getenv("IMMOCO_PIPELINE") != nullptr;
@@ -666,12 +711,7 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
       if (hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
     if (graph) hipGraphDestroy(graph);
   };
-  // K iterations per graph launch (everything iteration-dependent is read through the device-side counter, so a
-  // graph of K iterations is K copies of the same nodes): removes K - 1 of every K graph launches with their
-  // root-fork delay and end-of-graph gap (rocprofv3 timeline: ~12 + 10 us of 1250).  The remainder runs on the
-  // single-iteration graph.  A/B switch (environment, read once): IMMOCO_GRAPH_K (default 8; 1 = one per launch).
-  static const int graph_k = [] { const char* e = getenv("IMMOCO_GRAPH_K"); const int k = e ? atoi(e) : 8; return k < 1 ? 1 : (k > 64 ? 64 : k); }();
-  const int GK = pipelined ? 1 : graph_k;
+  const int GK = pipelined ? 1 : graph_k();
   s->graph_active = 0;
   if (s->cfg.use_graph) {
     std::vector<const void*> key = {kspace_in,  col_group,   params_image, params_motion,
@@ -703,10 +743,141 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
     ++j;
   }
   if (pipelined && (rc = run_steps_forked(s, arrange(all, Order::Epilogue), q))) return rc;   // Adam steps of the last iteration
-  // tensors of the LAST forward pass (immoco.py:203-206)
-  if (out_image) IMMOCO_CHECK_HIP(hipMemcpyAsync(out_image, s->image, (size_t)s->P * 8, hipMemcpyDeviceToDevice, q));
-  if (out_kspace && (rc = launch_transpose_c64(s->kout, out_kspace, s->cfg.W, s->cfg.H, q))) return rc;
+  if ((rc = finish_slice(s, q, a))) return rc;
   return sync_out ? leave(s, caller) : IMMOCO_OK;
+}
+
+// ---- two slices, one graph (BASELINE config 3, cfg.batch_pair) ------------------------------------------------
+// Slices A and B (workspaces `A` = the solver itself and `B` = its first lane) advance through the SAME iteration
+// index inside one captured graph.  Two slices merely kept in flight side by side (batch_lanes, round 2) are
+// slower than slice after slice: their hash-grid gathers evict each other's level slices from the XCD L2s.  Here
+// the four gather kernels of a double iteration - motion encode forward (E) and backward (C) of either slice -
+// run on ONE stream in the fixed order  E_A, E_B, C_A, C_B, E_A(next) ...  so that never two of them run at once,
+// and everything else of a slice (image chain, MLPs on the matrix cores, warp, FFTs, losses, Adam) runs on that
+// slice's own stream BESIDE the other slice's gather, in the issue slots and HBM bandwidth the gather leaves idle:
+//     q  : E_A ------ E_B ------ C_A ------ C_B ------ E_A' ...
+//     pA : img_A  |E_A| N_A --------|  |C_A| D_A img_A' ...
+//     pB :      img_B      |E_B| N_B --------|  |C_B| D_B ...
+// (N = motion MLP forward, warp, FFTs, losses, warp backward, motion MLP backward; D = Adam steps + image backward).
+// Every dependency is an event between q (the capture's origin stream) and one of the two side streams, and a side
+// stream only continues after it has waited for q again: the fork / join / fork-again pattern of the single-slice
+// graph (HIP's stream capture crashes in hipStreamEndCapture on nested forks and on sibling-to-sibling waits).
+int solve_pair(immoco_solver* A, immoco_solver* B, const SliceArgs& a, const SliceArgs& b, int32_t iters, float lr,
+               const float* lambda_sched, int32_t step0) {
+  int rc;
+  if ((rc = check_slice(A, a, iters, lambda_sched, step0)) || (rc = check_slice(B, b, iters, lambda_sched, step0))) return rc;
+  IMMOCO_REQUIRE(A->cfg.nM > 0, "solver_solve_batch: paired mode needs motion groups");
+  hipStream_t q = A->stream;
+  for (hipEvent_t& ev : A->ev_pair)
+    if (!ev) IMMOCO_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  // all per-solve initialisation of both workspaces on A's stream
+  if ((rc = prepare_slice(A, q, a, iters, lr, lambda_sched, step0)) ||
+      (rc = prepare_slice(B, q, b, iters, lr, lambda_sched, step0)))
+    return rc;
+  const Bind ba{A->kin_t, a.cg, a.pi, a.pm, a.ai, a.am, a.loss}, bb{B->kin_t, b.cg, b.pi, b.pm, b.ai, b.am, b.loss};
+  struct Lists {
+    std::vector<Step> img, e, n, c, d;   // image forward | E | N | C | D
+    hipStream_t p;
+    hipEvent_t ev_pre, ev_e, ev_n, ev_c, ev_d;
+  };
+  auto make_lists = [](const std::vector<Step>& all, hipStream_t p, hipEvent_t* ev) {
+    Lists l;
+    for (const Step& st : all) {
+      if (st.group == 0) l.img.push_back(st);
+      else if (strcmp(st.name, "motion_encode_fwd") == 0) l.e.push_back(st);
+      else if (st.group == 1 || st.group == 2) l.n.push_back(st);   // motion_mlp_fwd, then the serial middle
+      else if (st.group == 3) l.c.push_back(st);
+    }
+    for (int g : {6, 4, 5})   // motion Adam first (the next E_A waits for it), then the image backward chain, tick
+      for (const Step& st : all)
+        if (st.group == g) l.d.push_back(st);
+    l.p = p;
+    l.ev_pre = ev[0]; l.ev_e = ev[1]; l.ev_n = ev[2]; l.ev_c = ev[3]; l.ev_d = ev[4];
+    return l;
+  };
+  const Lists LA = make_lists(build_steps(A, ba, true), A->side, A->ev_pair), LB = make_lists(build_steps(B, bb, true), B->side, A->ev_pair + 5);
+  // one double iteration; again: a previous double iteration of this capture / eager sequence has recorded ev_d
+  auto double_iteration = [&](bool again) -> int {
+    int r;
+    auto encode_fwd = [&](const Lists& l) -> int {   // q: [wait D(prev)] ; pre ; E ; record | p: wait pre ; img
+      if (again) IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, l.ev_d, 0));
+      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_pre, q));
+      IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_pre, 0));
+      int rr;
+      if ((rr = run_steps(l.img, l.p)) || (rr = run_steps(l.e, q))) return rr;
+      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_e, q));
+      return IMMOCO_OK;
+    };
+    auto middle = [&](const Lists& l) -> int {       // p: wait E ; N ; record
+      IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_e, 0));
+      int rr;
+      if ((rr = run_steps(l.n, l.p))) return rr;
+      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_n, l.p));
+      return IMMOCO_OK;
+    };
+    auto encode_bwd = [&](const Lists& l) -> int {   // q: wait N ; C ; record | p: wait C ; D ; record
+      IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, l.ev_n, 0));
+      int rr;
+      if ((rr = run_steps(l.c, q))) return rr;
+      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_c, q));
+      IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_c, 0));
+      if ((rr = run_steps(l.d, l.p))) return rr;
+      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_d, l.p));
+      return IMMOCO_OK;
+    };
+    if ((r = encode_fwd(LA)) || (r = middle(LA)) || (r = encode_fwd(LB)) || (r = middle(LB)) || (r = encode_bwd(LA)) ||
+        (r = encode_bwd(LB)))
+      return r;
+    return IMMOCO_OK;
+  };
+  auto sequence = [&](int reps) -> int {
+    int r = IMMOCO_OK;
+    for (int k = 0; k < reps && r == IMMOCO_OK; ++k) r = double_iteration(k > 0);
+    if (r) return r;
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, LA.ev_d, 0));   // both side streams join the origin
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, LB.ev_d, 0));
+    return IMMOCO_OK;
+  };
+  auto capture = [&](hipGraphExec_t* out, int reps) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal) != hipSuccess) return;
+    const int r = sequence(reps);
+    const hipError_t e2 = hipStreamEndCapture(q, &graph);
+    if (r == IMMOCO_OK && e2 == hipSuccess && graph)
+      if (hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
+    if (graph) hipGraphDestroy(graph);
+  };
+  const int GK = graph_k();
+  bool graph_ok = false;
+  if (A->cfg.use_graph) {
+    std::vector<const void*> key = {a.kin, a.cg, a.pi, a.pm, a.ai, a.am, a.loss, A->sched,
+                                    b.kin, b.cg, b.pi, b.pm, b.ai, b.am, b.loss, B->sched, B};
+    sweep_retired(A, false);
+    if (!A->pg1 || key != A->pkey || (iters >= GK && GK > 1 && !A->pgk)) {
+      retire_graph(A);
+      capture(&A->pg1, 1);
+      if (A->pg1 && GK > 1 && iters >= GK) capture(&A->pgk, GK);
+      (void)hipGetLastError();
+      A->pkey = key;
+      A->gkey.clear();   // retire_graph dropped the single-slice graphs too
+    }
+    graph_ok = A->pg1 != nullptr;
+  }
+  A->graph_active = graph_ok ? 1 : 0;
+  for (int j = 0; j < iters;) {
+    if (graph_ok && A->pgk && GK > 1 && iters - j >= GK) {
+      IMMOCO_CHECK_HIP(hipGraphLaunch(A->pgk, q));
+      j += GK;
+    } else if (graph_ok) {
+      IMMOCO_CHECK_HIP(hipGraphLaunch(A->pg1, q));
+      ++j;
+    } else {
+      if ((rc = sequence(1))) return rc;
+      ++j;
+    }
+  }
+  if ((rc = finish_slice(A, q, a)) || (rc = finish_slice(B, q, b))) return rc;
+  return IMMOCO_OK;
 }
 }  // namespace
 
@@ -729,6 +900,7 @@ namespace {
 int make_lane(immoco_solver* parent, immoco_solver** out) {
   immoco_solver_cfg cfg = parent->cfg;
   cfg.batch_lanes = 0;
+  cfg.batch_pair = 0;
   immoco_solver* lane = nullptr;
   int rc = immoco_solver_create(&cfg, &lane);
   if (rc) return rc;
@@ -756,6 +928,33 @@ extern "C" int immoco_solver_solve_batch(immoco_solver_t s, int32_t B, const flo
   IMMOCO_REQUIRE(B >= 0, "solver_solve_batch: negative batch size %d", B);
   IMMOCO_REQUIRE(B == 0 || s->lattice_set, "solver_solve_batch: call immoco_solver_set_lattice first");
   const int64_t P2 = 2 * s->P, W = s->cfg.W;
+  if (s->cfg.batch_pair && s->cfg.nM > 0 && B >= 2) {
+    if (s->lanes.empty()) {
+      immoco_solver* lane = nullptr;
+      int rc = make_lane(s, &lane);
+      if (rc) return rc;
+      s->lanes.push_back(lane);
+    }
+    auto args = [&](int32_t i) {
+      return SliceArgs{kspace_in ? kspace_in + i * P2 : nullptr, col_group ? col_group + i * W : nullptr,
+                       params_image ? params_image + i * s->n_params_img : nullptr,
+                       params_motion ? params_motion + i * s->n_params_mot : nullptr,
+                       adam_image ? adam_image + 2 * i * s->n_params_img : nullptr,
+                       adam_motion ? adam_motion + 2 * i * s->n_params_mot : nullptr,
+                       out_image ? out_image + i * P2 : nullptr, out_kspace ? out_kspace + i * P2 : nullptr,
+                       loss_hist ? loss_hist + (int64_t)i * iters : nullptr};
+    };
+    int rc = enter(s, as_stream(stream));
+    for (int32_t i = 0; rc == IMMOCO_OK && i + 1 < B; i += 2)
+      rc = solve_pair(s, s->lanes[0], args(i), args(i + 1), iters, lr, lambda_sched, step0);
+    if (rc == IMMOCO_OK && (B & 1)) {
+      const SliceArgs l = args(B - 1);
+      rc = solve_impl(s, l.kin, l.cg, l.pi, l.pm, l.ai, l.am, iters, lr, lambda_sched, step0, l.out_image, l.out_kspace,
+                      l.loss, stream, false, false);
+    }
+    const int rc2 = leave(s, as_stream(stream));   // also on errors: queued work still uses the caller's buffers
+    return rc ? rc : rc2;
+  }
   const int n_lanes = std::max(1, std::min<int>(s->cfg.batch_lanes, B));
   while ((int)s->lanes.size() < n_lanes - 1) {  // lane 0 is the solver itself
     immoco_solver* lane = nullptr;

@@ -147,7 +147,7 @@ class _SolverHandle:
     """RAII wrapper of immoco_solver_t; cached per (device, H, W, nM)."""
 
     def __init__(self, device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, table_fp16=False,
-                 batch_lanes=0, mlp_fp16=False, serial_chains=None):
+                 batch_lanes=0, mlp_fp16=False, serial_chains=None, batch_pair=False):
         self.device, self.H, self.W, self.nM = device, H, W, nM
         self.image_grid = L.grid_cfg(2, encoding_config)
         self.motion_grid = L.grid_cfg(3, encoding_config)
@@ -155,7 +155,8 @@ class _SolverHandle:
         self.motion_mlp = L.mlp_cfg(32, 2, mot_network_config)
         cfg = L.SolverCfg(H, W, nM, self.image_grid, self.motion_grid, self.image_mlp, self.motion_mlp,
                           1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts),
-                          2 if serial_chains is None else (1 if serial_chains else 0), 1 if table_fp16 else 0, int(batch_lanes), 1 if mlp_fp16 else 0)
+                          2 if serial_chains is None else (1 if serial_chains else 0), 1 if table_fp16 else 0, int(batch_lanes), 1 if mlp_fp16 else 0,
+                          1 if batch_pair else 0)
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(L.lib().immoco_solver_create(C.byref(cfg), C.byref(self.handle)), "solver_create")
@@ -261,16 +262,16 @@ _SOLVERS = {}
 
 
 def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_parts=0, instance=0,
-               table_fp16=False, batch_lanes=0, mlp_fp16=False, serial_chains=None) -> _SolverHandle:
+               table_fp16=False, batch_lanes=0, mlp_fp16=False, serial_chains=None, batch_pair=False) -> _SolverHandle:
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance),
-           bool(table_fp16), int(batch_lanes), bool(mlp_fp16), serial_chains)
+           bool(table_fp16), int(batch_lanes), bool(mlp_fp16), serial_chains, bool(batch_pair))
     s = _SOLVERS.get(key)
     if s is None:
         s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts, table_fp16,
-                                          batch_lanes, mlp_fp16, serial_chains)
+                                          batch_lanes, mlp_fp16, serial_chains, batch_pair)
     return s
 
 
@@ -342,12 +343,14 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
 
 def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate=1e-2, lambda_ge=1e-2, *, seed=1337,
                                    norm_scale=16000.0, lambda_rule="immoco", return_loss=False, use_graph=True,
-                                   table_fp16=False, lanes=1, mlp_fp16=False):
+                                   table_fp16=False, lanes=1, mlp_fp16=False, pair=False):
     """``imcoco_motion_correction`` for a batch (BASELINE config 3: B slices resident on one GPU):
     ``kspaces [B, H, W] c64`` and one ``masks [nM_i, H, W]`` per slice.  Slices with the same number of
     movement groups share one ``immoco_solver_solve_batch`` call (parameters, Adam state and outputs live in
     ``[B_g, ...]`` tensors; 305 MB of fp32 state per slice); ``lanes`` > 1 keeps that many slices in flight side by
-    side (``immoco_solver_cfg.batch_lanes``; slower than slice after slice on MI355X).  Returns ``(image_prior [B, H, W],
+    side (``immoco_solver_cfg.batch_lanes``; slower than slice after slice on MI355X); ``pair=True``
+    solves two slices at a time inside one graph with their hash-grid gathers serialised by events
+    (``immoco_solver_cfg.batch_pair``).  Returns ``(image_prior [B, H, W],
     kspace_foward_model [B, H, W])`` (+ ``loss [B, iters]`` with ``return_loss``), slice i initialised like a
     single call with the same ``seed``."""
     if kspaces.dim() != 3 or len(masks_list) != kspaces.shape[0]:
@@ -365,7 +368,7 @@ def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate
             raise L.ImmocoError(f"masks[{i}] shape {tuple(m.shape)} does not match kspaces {(H, W)}")
         by_nm.setdefault(int(m.shape[0]), []).append(i)
     for nM, idx in sorted(by_nm.items()):
-        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16, lanes, mlp_fp16=mlp_fp16)
+        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16, lanes, mlp_fp16=mlp_fp16, batch_pair=pair)
         Bg = len(idx)
         k = kspaces[idx].to(torch.complex64).contiguous()
         kin = torch.empty_like(k)

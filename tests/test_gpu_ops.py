@@ -1210,6 +1210,34 @@ def test_batch_of_slices_independent(env):
     assert abs(a0[0] - b0[0]) > 1e-3 * a0[0]                    # different slice -> different problem
 
 
+@pytest.mark.parametrize("mlp_fp16", [False, True])
+def test_batch_pair_mode_matches_single_solves(env, mlp_fp16):
+    """BASELINE config 3 building block, paired mode (immoco_solver_cfg.batch_pair): two slices advance inside ONE
+    captured graph, their four hash-grid gather kernels chained by events, everything else free to overlap.  Each
+    slice must come out as if solved alone: the first iterations' losses agree to fp32 summation accuracy with
+    per-slice calls (atomics make later iterations diverge like any two runs), the last slice of an odd batch takes
+    the single-slice path, and the returned images are those of each slice's own last forward."""
+    pkg, L, orc = env
+    from oracle import synth_cpu
+    H, nM, B, iters = 96, 3, 3, 24
+    sl = [synth_cpu.make_slice(H, H, nM, 20 + i) for i in range(B + 3)]
+    masks = [pkg.extract_movement_groups(s["lines"].cuda(), make_list=True) for s in sl]
+    keep = [i for i in range(len(sl)) if masks[i].shape[0] == masks[0].shape[0]][:B]
+    if len(keep) < B:
+        pytest.skip("synthetic slices ended up with different group counts")
+    ks = torch.stack([sl[i]["kspace"] for i in keep]).cuda()
+    ms = [masks[i] for i in keep]
+    imgs, kfm, loss = pkg.imcoco_motion_correction_batch(ks, ms, iters=iters, return_loss=True, pair=True, mlp_fp16=mlp_fp16)
+    for j in range(B):
+        i1, k1, l1 = pkg.imcoco_motion_correction(ks[j], ms[j], iters=iters, return_loss=True, mlp_fp16=mlp_fp16)
+        a, b = loss[j].cpu().numpy(), l1.cpu().numpy()
+        np.testing.assert_allclose(a[:5], b[:5], rtol=1e-3 if mlp_fp16 else 1e-4)
+        np.testing.assert_allclose(a, b, rtol=0.05)
+        e = float((imgs[j] - i1).abs().max() / i1.abs().max())
+        assert e < 0.1, (j, e)
+    assert float((imgs[0] - imgs[1]).abs().max()) > 0      # different slices, different results
+
+
 def _c2_slice1(pkg, golden):
     """Slice 1 of config C2 exactly as the CPU-oracle records saw it (tests/golden/c2_slice1_input.npz)."""
     from miccai24_immoco_amd import synth
