@@ -240,14 +240,16 @@ constexpr int EPT = 16;                  // entries per thread per chunk
 // dL/denc window in the XCD's L2 - 0.482 -> 0.464 ms (4 parts), 0.462 -> 0.448 ms (8 parts, but Adam then reads
 // eight partial tables: +0.04 ms).  The gradient tiles are written once and read by Adam much later: non-temporal
 // stores too.  Same box, 4 parts: plain 0.4749, nt loads 0.4524, nt stores 0.4615, both 0.4474 ms.
-template <int DIMS, bool PAIR>  // DIMS names the instantiation (2: image grid, 3: motion grid) in profiles
+// DH: dL/d enc is stored as packed halves (one 4-byte word per point and level, still multiplied by the fp16 MLP
+// backward's loss scale: mlp_f16.hip); the gather is 4 bytes, the sums are unscaled (out_scale) on the way out.
+template <int DIMS, bool PAIR, bool DH = false>  // DIMS names the instantiation (2: image grid, 3: motion grid) in profiles
 __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t part_size,
                                                       const BwdItem* __restrict__ items,
                                                       const uint2* __restrict__ entries,
                                                       const float2* __restrict__ denc /*[L][n]*/,
                                                       float* __restrict__ dtable, int64_t part_stride,
                                                       int n_tables, int zeroed, const float* __restrict__ f0tab,
-                                                      int n0, uint32_t hw, float inv_hw, int nt) {
+                                                      int n0, uint32_t hw, float inv_hw, int nt, float out_scale) {
   constexpr int NS = PAIR ? 4 : 2;                     // sums per run: (even.x, even.y, odd.x, odd.y) or (x, y)
   __shared__ __attribute__((aligned(16))) float accA[2 * SLOTS_PER_ITEM];  // plain stores: one per run
   __shared__ __attribute__((aligned(16))) float accB[2 * SLOTS_PER_ITEM];  // float atomics: the leftovers
@@ -263,6 +265,8 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
   __syncthreads();
   const uint32_t part = it.part_shared & 0xFFFFu;
   const float2* __restrict__ dl = denc + (int64_t)it.level * n_points + (int64_t)part * part_size;
+  const __half2* __restrict__ dlh =
+      reinterpret_cast<const __half2*>(denc) + (int64_t)it.level * n_points + (int64_t)part * part_size;
   const uint32_t p_off = (uint32_t)((int64_t)part * part_size);
   const int lane = tid & 63, wave = tid >> 6;
   const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(entries + it.pe0);
@@ -302,8 +306,16 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
       for (int j = 0; j < EPT / 2; ++j) q[j] = ld((size_t)(wc + 4) * (WAVE_CHUNK / 2) + j * 64 + lane);
     }
     float2 g[EPT];
+    if (DH) {
+      __half2 gh[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) g[k] = dl[key[k] >> SLOT_BITS];
+      for (int k = 0; k < EPT; ++k) gh[k] = dlh[key[k] >> SLOT_BITS];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) g[k] = __half22float2(gh[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) g[k] = dl[key[k] >> SLOT_BITS];
+    }
     // run-length accumulate; the head run (the one that contains entry 0) is kept aside, runs in the
     // middle of the lane are stored at once, the tail run stays in s[]
     const uint32_t first = (key[0] & (SLOTS_PER_ITEM - 1)) >> (PAIR ? 1 : 0);
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
   float* __restrict__ out = dtable + (size_t)(part % (uint32_t)n_tables) * part_stride + (size_t)it.s0 * 2;
   if ((it.part_shared >> 16) & 1u) {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
-      const float v = accA[i] + accB[i];
+      const float v = (accA[i] + accB[i]) * (DH ? out_scale : 1.f);
       if (v != 0.f) unsafeAtomicAdd(out + i, v);
     }
   } else if (zeroed && ((it.part_shared >> 17) & 1u)) {
@@ -388,13 +400,14 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
     // plan build, not per round: a block whose only items sit in a later round (the wrapped-stride levels
     // index by the m cell, so different rounds hit different blocks) would otherwise accumulate for ever.
     if (nt & 2) {
-      for (int i = tid; i < 2 * (int)it.ns; i += 256) __builtin_nontemporal_store(accA[i] + accB[i], out + i);
+      for (int i = tid; i < 2 * (int)it.ns; i += 256)
+        __builtin_nontemporal_store((accA[i] + accB[i]) * (DH ? out_scale : 1.f), out + i);
     } else {
-      for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = accA[i] + accB[i];
+      for (int i = tid; i < 2 * (int)it.ns; i += 256) out[i] = (accA[i] + accB[i]) * (DH ? out_scale : 1.f);
     }
   } else {
     for (int i = tid; i < 2 * (int)it.ns; i += 256) {
-      const float v = accA[i] + accB[i];
+      const float v = (accA[i] + accB[i]) * (DH ? out_scale : 1.f);
       if (v != 0.f) out[i] += v;
     }
   }
@@ -656,9 +669,10 @@ int64_t csr_plan_bytes(const CsrPlan* p) { return p ? p->bytes : 0; }
 int64_t csr_plan_entries(const CsrPlan* p) { return p ? (int64_t)p->n_entries : 0; }
 int csr_plan_parts(const CsrPlan* p) { return p ? p->n_parts : 1; }
 int csr_plan_tables(const CsrPlan* p) { return p ? p->n_tables : 1; }
-// parts for a lattice of n points: one level slice of dL/denc (8 B per point) per part ~ 2 MB
-int csr_auto_parts(int64_t n_points) {
-  const int64_t slice = n_points * 8;
+// parts for a lattice of n points: one level slice of dL/denc (8 B per point in fp32, 4 B as packed halves) per
+// part ~ 2 MB
+int csr_auto_parts(int64_t n_points, int bytes_per_point) {
+  const int64_t slice = n_points * bytes_per_point;
   int parts = 1;
   while (parts < 256 && slice > (int64_t)parts * (2 << 20)) parts *= 2;
   return parts;
@@ -672,7 +686,7 @@ const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n) {
 // that the buffers hold zeros or stale values of the same plan (plain stores); otherwise the
 // results are accumulated.
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride, int zeroed,
-                   hipStream_t st) {
+                   hipStream_t st, bool denc_half, float out_scale) {
   if (!pl || pl->n_items == 0) return IMMOCO_OK;
   const int64_t n = (int64_t)pl->nM * pl->H * pl->W;
   const uint32_t hw = (uint32_t)pl->H * (uint32_t)pl->W;
@@ -692,13 +706,20 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
   for (size_t r = 0; r < pl->rounds.size(); ++r) {
     const uint32_t first = pl->rounds[r].first, cnt = pl->rounds[r].second;
     if (cnt == 0) continue;
-#define IMMOCO_CSR_BWD(D, PAIR)                                                                                 \
-  csr_bwd_kernel<D, PAIR><<<cnt, 256, pad_lds, st>>>(n, pl->part_size, pl->items + first, pl->entries,                 \
-                                                       (const float2*)denc_level_major, dtable, part_stride,     \
-                                                       pl->n_tables, zeroed, pl->f0tab, pl->axn[0], hw, 1.0f / (float)hw, nt)
-    if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true);
-    else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false);
-    else IMMOCO_CSR_BWD(2, false);
+#define IMMOCO_CSR_BWD(D, PAIR, DH)                                                                             \
+  csr_bwd_kernel<D, PAIR, DH><<<cnt, 256, pad_lds, st>>>(n, pl->part_size, pl->items + first, pl->entries,             \
+                                                           (const float2*)denc_level_major, dtable, part_stride, \
+                                                           pl->n_tables, zeroed, pl->f0tab, pl->axn[0], hw,      \
+                                                           1.0f / (float)hw, nt, out_scale)
+    if (denc_half) {
+      if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true, true);
+      else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false, true);
+      else IMMOCO_CSR_BWD(2, false, true);
+    } else {
+      if (pl->dims == 3 && pl->pair_merge) IMMOCO_CSR_BWD(3, true, false);
+      else if (pl->dims == 3) IMMOCO_CSR_BWD(3, false, false);
+      else IMMOCO_CSR_BWD(2, false, false);
+    }
 #undef IMMOCO_CSR_BWD
   }
   IMMOCO_LAUNCH_CHECK();
@@ -749,5 +770,5 @@ extern "C" int64_t immoco_grid_plan_bytes(immoco_grid_plan_t p) { return p ? csr
 extern "C" int immoco_grid_plan_bwd(immoco_grid_plan_t p, const float* denc_level_major, float* dtable,
                                     void* stream) {
   IMMOCO_REQUIRE(p && denc_level_major && dtable, "grid_plan_bwd: NULL argument");
-  return launch_csr_bwd(p->plan, denc_level_major, dtable, 0, 0, as_stream(stream));
+  return launch_csr_bwd(p->plan, denc_level_major, dtable, 0, 0, as_stream(stream), false, 1.f);
 }

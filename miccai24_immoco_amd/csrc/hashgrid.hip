@@ -111,7 +111,21 @@ static int enc_store_sc1() {
 
 // mode 0: plain store; 1: agent-scope relaxed store = `global_store ... sc1` (write through, line dropped from L2);
 // 2: non-temporal store (`nt`)
+// mode & 16: the encoding is stored as packed halves (round to nearest even), one 4-byte word per (point, level) -
+// tiny-cuda-nn's encoding output precision, the input precision of the fp16 MLP kernels (mlp_f16.hip); `dst` then
+// counts 4-byte words
 __device__ __forceinline__ void store_enc(float* dst, float2 e, int mode) {
+  if (mode & 16) {
+    typedef _Float16 h2s __attribute__((ext_vector_type(2)));
+    typedef float f2s __attribute__((ext_vector_type(2)));
+    const f2s x = {e.x, e.y};
+    const h2s hv = __builtin_convertvector(x, h2s);
+    uint32_t u;
+    __builtin_memcpy(&u, &hv, 4);
+    if ((mode & 15) == 2) __builtin_nontemporal_store(u, reinterpret_cast<uint32_t*>(dst));
+    else *reinterpret_cast<uint32_t*>(dst) = u;
+    return;
+  }
   if (mode == 1) {
     union { float2 f; uint64_t u; } cv;
     cv.f = e;
@@ -351,12 +365,12 @@ static int fwd_points_per_thread(int64_t n) {
 
 template <typename TAB>
 static bool launch_fwd_lat3(const Levels& lv, const Lattice& lat, int64_t n, const TAB* t, float* enc, int64_t ps,
-                            int64_t ls, hipStream_t st) {
+                            int64_t ls, hipStream_t st, int mode) {
   const int K = fwd_points_per_thread(n);
   if (lv.dims != 3 || K == 1 || n < 256 * 64) return false;
   dim3 grid((unsigned)cdiv(n, 256 * K), lv.n_levels);
-  if (K == 2) hashgrid_fwd_lat3_kernel<TAB, 2><<<grid, 256, 0, st>>>(lv, lat, n, t, enc, ps, ls, enc_store_sc1());
-  else hashgrid_fwd_lat3_kernel<TAB, 4><<<grid, 256, 0, st>>>(lv, lat, n, t, enc, ps, ls, enc_store_sc1());
+  if (K == 2) hashgrid_fwd_lat3_kernel<TAB, 2><<<grid, 256, 0, st>>>(lv, lat, n, t, enc, ps, ls, mode);
+  else hashgrid_fwd_lat3_kernel<TAB, 4><<<grid, 256, 0, st>>>(lv, lat, n, t, enc, ps, ls, mode);
   return true;
 }
 
@@ -410,9 +424,9 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(Levels lv, con
 }
 
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
-                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st) {
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st, bool half_out) {
   if (n == 0) return IMMOCO_OK;
-  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "encoding strides must be even (float2 stores)");
+  IMMOCO_REQUIRE(half_out || ((ps % 2) == 0 && (ls % 2) == 0), "encoding strides must be even (float2 stores)");
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
   Lattice L{};
   if (lat) {
@@ -420,17 +434,18 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
     int rc = check_lattice(lv, L, n);
     if (rc) return rc;
   }
+  const int mode = enc_store_sc1() | (half_out ? 16 : 0);
   const float2* t = reinterpret_cast<const float2*>(table);
-  if (lat && launch_fwd_lat3<float2>(lv, L, n, t, enc, ps, ls, st)) {
+  if (lat && launch_fwd_lat3<float2>(lv, L, n, t, enc, ps, ls, st, mode)) {
     IMMOCO_LAUNCH_CHECK();
     return IMMOCO_OK;
   }
   if (lv.dims == 2) {
-    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
-    else hashgrid_fwd_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
+    if (lat) hashgrid_fwd_kernel<2, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, mode);
+    else hashgrid_fwd_kernel<2, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, mode);
   } else {
-    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
-    else hashgrid_fwd_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, enc_store_sc1());
+    if (lat) hashgrid_fwd_kernel<3, true><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, mode);
+    else hashgrid_fwd_kernel<3, false><<<grid, block, 0, st>>>(lv, coords, L, n, t, enc, ps, ls, mode);
   }
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
@@ -438,20 +453,21 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
 
 // forward from the fp16 shadow table (lattice mode only: the solver's path)
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
-                             int64_t ps, int64_t ls, hipStream_t st) {
+                             int64_t ps, int64_t ls, hipStream_t st, bool half_out) {
   if (n == 0) return IMMOCO_OK;
   {
     int rc = check_lattice(lv, lat, n);
     if (rc) return rc;
   }
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels), block(256);
+  const int mode = enc_store_sc1() | (half_out ? 16 : 0);
   const __half2* t = reinterpret_cast<const __half2*>(table_half2);
-  if (launch_fwd_lat3<__half2>(lv, lat, n, t, enc, ps, ls, st)) {
+  if (launch_fwd_lat3<__half2>(lv, lat, n, t, enc, ps, ls, st, mode)) {
     IMMOCO_LAUNCH_CHECK();
     return IMMOCO_OK;
   }
-  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());
-  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, enc_store_sc1());
+  if (lv.dims == 2) hashgrid_fwd_kernel<2, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, mode);
+  else hashgrid_fwd_kernel<3, true, __half2><<<grid, block, 0, st>>>(lv, nullptr, lat, n, t, enc, ps, ls, mode);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

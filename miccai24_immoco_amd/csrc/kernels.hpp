@@ -12,10 +12,11 @@ struct Lattice {
 };
 
 // hashgrid.hip
+// half_out: the encoding is written as packed halves, one 4-byte word per (point, level); ps / ls in 4-byte words
 int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
-                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st);
+                        const float* table, float* enc, int64_t ps, int64_t ls, hipStream_t st, bool half_out = false);
 int launch_hashgrid_fwd_half(const Levels& lv, const Lattice& lat, int64_t n, const void* table_half2, float* enc,
-                             int64_t ps, int64_t ls, hipStream_t st);
+                             int64_t ps, int64_t ls, hipStream_t st, bool half_out = false);
 
 int launch_f32_to_half(const float* in, void* out_half, int64_t n, hipStream_t st);
 int launch_hashgrid_bwd(const Levels& lv, const float* coords, const Lattice* lat, int64_t n,
@@ -40,11 +41,13 @@ int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
 
 // mlp_f16.hip — tiny-cuda-nn's operand precision: fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16);
 // the backward scales dout by `scale` (tcnn's loss scale, 128) before rounding it to fp16
+// enc_half: the encoding (and dL/d enc, which stays scaled by `scale`) is stored as packed halves, one 4-byte word per
+// (point, level); ps / ls are then in 4-byte words
 int launch_mlp_fwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
-                       const float* w1, const float* w2, float* out, hipStream_t st);
+                       const float* w1, const float* w2, float* out, hipStream_t st, bool enc_half = false);
 int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                        const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                       hipStream_t st, int64_t dout_plane, float scale);
+                       hipStream_t st, int64_t dout_plane, float scale, bool enc_half = false);
 
 // warp.hip
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st);
@@ -106,7 +109,7 @@ int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float
 struct CsrPlan;
 int csr_plan_build(const Levels& lv, int nM, int H, int W, const float* const* axes, const int32_t* axn,
                    int n_parts, int n_tables, CsrPlan** out, hipStream_t st);
-int csr_auto_parts(int64_t n_points);
+int csr_auto_parts(int64_t n_points, int bytes_per_point = 8);
 int csr_plan_tables(const CsrPlan* p);
 void csr_plan_free(CsrPlan* p);
 int64_t csr_plan_bytes(const CsrPlan* p);
@@ -115,8 +118,9 @@ int csr_plan_parts(const CsrPlan* p);
 // slot blocks that receive gradients: {first slot, n slots | shared << 31} (device array); shared blocks are
 // flushed with atomics and have to be cleared by the consumer, unlisted blocks never get a gradient
 const uint2* csr_plan_touched(const CsrPlan* p, uint32_t* n);
+// denc_half: dL/d enc is stored as packed halves (4-byte words) scaled by 1 / out_scale
 int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtable, int64_t part_stride,
-                   int zeroed, hipStream_t st);
+                   int zeroed, hipStream_t st, bool denc_half = false, float out_scale = 1.f);
 
 // masks.hip
 int launch_extract_groups(const uint8_t* lines, int n, int32_t* col_group, int32_t* n_groups, hipStream_t st);

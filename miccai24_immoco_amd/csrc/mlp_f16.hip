@@ -114,29 +114,48 @@ __device__ __forceinline__ void build_w2_frags(const float* __restrict__ w2, h8v
   }
 }
 
-// enc of point p as the B operand of L1: step s, elem i = enc[p][feature 16s + 8h + i] = level 8s + 4h + (i>>1)
+// enc of point p as the B operand of L1: step s, elem i = enc[p][feature 16s + 8h + i] = level 8s + 4h + (i>>1).
+// EH = false: the encoding is stored in fp32 (a float2 per point and level; strides in floats) and rounded here;
+// EH = true: it is stored as packed halves (one 4-byte word per point and level; strides in 4-byte words, the
+// solver's layout with cfg.mlp_fp16: tiny-cuda-nn's encoding output is fp16 too) and the four words of a k-step
+// ARE the operand.
+template <bool EH>
 struct EncRaw {
-  float2 v[8];   // [2 s + ...]: v[4s + q] = level 8s + 4h + q
+  float2 v[EH ? 1 : 8];      // [4s + q] = level 8s + 4h + q
+  uint32_t w[EH ? 8 : 1];
 };
+template <bool EH>
 __device__ __forceinline__ void load_enc_raw(const float* in, int64_t ps, int64_t ls, int64_t p, int64_t n, int h,
-                                             EncRaw& e) {
+                                             EncRaw<EH>& e) {
   const int64_t pc = p < n ? p : n - 1;
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      e.v[4 * s + q] = *reinterpret_cast<const float2*>(in + pc * ps + (int64_t)(8 * s + 4 * h + q) * ls);
+    for (int q = 0; q < 4; ++q) {
+      if (EH) e.w[EH ? 4 * s + q : 0] = reinterpret_cast<const uint32_t*>(in)[pc * ps + (int64_t)(8 * s + 4 * h + q) * ls];
+      else e.v[EH ? 0 : 4 * s + q] = *reinterpret_cast<const float2*>(in + pc * ps + (int64_t)(8 * s + 4 * h + q) * ls);
+    }
 }
-__device__ __forceinline__ void enc_frags(const EncRaw& e, bool valid, h8v (&eb)[2]) {
+template <bool EH>
+__device__ __forceinline__ void enc_frags(const EncRaw<EH>& e, bool valid, h8v (&eb)[2]) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    float v[8];
+    if (EH) {
+      uint4 q4;
+      q4.x = valid ? e.w[EH ? 4 * s : 0] : 0u;
+      q4.y = valid ? e.w[EH ? 4 * s + 1 : 0] : 0u;
+      q4.z = valid ? e.w[EH ? 4 * s + 2 : 0] : 0u;
+      q4.w = valid ? e.w[EH ? 4 * s + 3 : 0] : 0u;
+      eb[s] = *reinterpret_cast<const h8v*>(&q4);
+    } else {
+      float v[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[2 * q] = valid ? e.v[4 * s + q].x : 0.f;
-      v[2 * q + 1] = valid ? e.v[4 * s + q].y : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        v[2 * q] = valid ? e.v[EH ? 0 : 4 * s + q].x : 0.f;
+        v[2 * q + 1] = valid ? e.v[EH ? 0 : 4 * s + q].y : 0.f;
+      }
+      eb[s] = pk8(v);
     }
-    eb[s] = pk8(v);
   }
 }
 
@@ -144,7 +163,7 @@ __device__ __forceinline__ void enc_frags(const EncRaw& e, bool valid, h8v (&eb)
 
 // ---------------------------------------------------------------------------------------------
 // forward: out[p][0..1] = W2h . half(act(W1h . half(enc[p])))
-template <int HID, int ACT>
+template <int HID, int ACT, bool EH>
 __global__ __launch_bounds__(256) void mlp_fwd_f16_kernel(const float* __restrict__ in, int64_t ps, int64_t ls,
                                                           int64_t n, const float* __restrict__ w1,
                                                           const float* __restrict__ w2, float* __restrict__ out,
@@ -159,13 +178,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_f16_kernel(const float* __restric
   build_w2_frags<HID>(w2, aw2, threadIdx.x);
   __syncthreads();
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
-  EncRaw nx;
-  if (wave_id < n_tiles) load_enc_raw(in, ps, ls, wave_id * 32 + r, n, h, nx);
+  EncRaw<EH> nx;
+  if (wave_id < n_tiles) load_enc_raw<EH>(in, ps, ls, wave_id * 32 + r, n, h, nx);
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
     const int64_t p = t * 32 + r;
     h8v eb[2];
-    enc_frags(nx, p < n, eb);
-    if (t + n_waves < n_tiles) load_enc_raw(in, ps, ls, (t + n_waves) * 32 + r, n, h, nx);
+    enc_frags<EH>(nx, p < n, eb);
+    if (t + n_waves < n_tiles) load_enc_raw<EH>(in, ps, ls, (t + n_waves) * 32 + r, n, h, nx);
     f32x16 o = {0.f};
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_f16_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // backward.  dout is scaled by `scale` (tcnn's loss scale) before it is rounded to fp16; d enc and the weight
 // gradients are unscaled in fp32 on the way out.
-template <int HID, int ACT>
+template <int HID, int ACT, bool EH>
 __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
     const float* in /* may alias din */, int64_t ps, int64_t ls, int64_t n, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ dout, float* din, float* __restrict__ dw1,
@@ -228,13 +247,13 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
   for (int jt = 0; jt < NJT; ++jt) dw1t[jt] = (f32x16){0.f};
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
-  EncRaw nx;
+  EncRaw<EH> nx;
   float2 nx_d = make_float2(0.f, 0.f);
   auto load_raw = [&](int64_t tt) {
     const int64_t q = tt * 32 + r;
     const int64_t qc = q < n ? q : n - 1;
     const float mq = q < n ? 1.f : 0.f;
-    load_enc_raw(in, ps, ls, q, n, h, nx);
+    load_enc_raw<EH>(in, ps, ls, q, n, h, nx);
     if (dout_plane) {  // wave-uniform
       nx_d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
     } else {
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
     const int64_t p = t * 32 + r;
     const bool valid = p < n;
     h8v eb[2];
-    enc_frags(nx, valid, eb);
+    enc_frags<EH>(nx, valid, eb);
     const h2v dpk = pk(nx_d.x * scale, nx_d.y * scale);
     const float d0 = (float)dpk[0], d1 = (float)dpk[1];
     if (t + n_waves < n_tiles) load_raw(t + n_waves);
@@ -329,9 +348,18 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int level = 4 * a + 2 * h;
-        *reinterpret_cast<float2*>(din + p * ps + (int64_t)level * ls) = make_float2(denc[4 * a] * inv, denc[4 * a + 1] * inv);
-        *reinterpret_cast<float2*>(din + p * ps + (int64_t)(level + 1) * ls) =
-            make_float2(denc[4 * a + 2] * inv, denc[4 * a + 3] * inv);
+        if (EH) {
+          // packed halves, STILL scaled by the loss scale (tcnn hands dL/d enc to the grid backward in fp16 and
+          // scaled; the consumer - csr_bwd_kernel - unscales in fp32 after the gather)
+          const h2v lo = pk(denc[4 * a], denc[4 * a + 1]), hi = pk(denc[4 * a + 2], denc[4 * a + 3]);
+          uint32_t* dw = reinterpret_cast<uint32_t*>(din);
+          dw[p * ps + (int64_t)level * ls] = *reinterpret_cast<const uint32_t*>(&lo);
+          dw[p * ps + (int64_t)(level + 1) * ls] = *reinterpret_cast<const uint32_t*>(&hi);
+        } else {
+          *reinterpret_cast<float2*>(din + p * ps + (int64_t)level * ls) = make_float2(denc[4 * a] * inv, denc[4 * a + 1] * inv);
+          *reinterpret_cast<float2*>(din + p * ps + (int64_t)(level + 1) * ls) =
+              make_float2(denc[4 * a + 2] * inv, denc[4 * a + 3] * inv);
+        }
       }
     }
   }
@@ -383,13 +411,17 @@ static size_t f16_bwd_smem(int hid) {
 }
 
 int launch_mlp_fwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
-                       const float* w1, const float* w2, float* out, hipStream_t st) {
+                       const float* w1, const float* w2, float* out, hipStream_t st, bool enc_half) {
   if (n == 0) return IMMOCO_OK;
-  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+  IMMOCO_REQUIRE(enc_half || ((ps % 2) == 0 && (ls % 2) == 0), "mlp input strides must be even");
   const int64_t n_tiles = cdiv(n, 32);
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_tiles, 4), 512);
   const size_t sm = f16_fwd_smem(cfg.n_hidden);
-#define IMMOCO_FWD(H, A) mlp_fwd_f16_kernel<H, A><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, out, n_tiles)
+#define IMMOCO_FWD(H, A)                                                                             \
+  do {                                                                                               \
+    if (enc_half) mlp_fwd_f16_kernel<H, A, true><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, out, n_tiles); \
+    else mlp_fwd_f16_kernel<H, A, false><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, out, n_tiles);         \
+  } while (0)
   if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH) IMMOCO_FWD(64, IMMOCO_ACT_TANH);
   else if (cfg.n_hidden == 64) IMMOCO_FWD(64, IMMOCO_ACT_RELU);
   else if (cfg.activation == IMMOCO_ACT_TANH) IMMOCO_FWD(256, IMMOCO_ACT_TANH);
@@ -399,7 +431,7 @@ int launch_mlp_fwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, i
   return IMMOCO_OK;
 }
 
-template <int HID, int ACT>
+template <int HID, int ACT, bool EH>
 static int launch_bwd_f16_t(const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1, const float* w2,
                             const float* dout, float* din, float* dw1, float* dw2, hipStream_t st,
                             int64_t dout_plane, float scale) {
@@ -409,29 +441,30 @@ static int launch_bwd_f16_t(const float* in, int64_t ps, int64_t ls, int64_t n, 
   const size_t sm = f16_bwd_smem(HID);
   static bool attr_set = false;
   if (!attr_set) {
-    IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_f16_kernel<HID, ACT>),
+    IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_f16_kernel<HID, ACT, EH>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     attr_set = true;
   }
-  mlp_bwd_f16_kernel<HID, ACT><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles,
-                                                      dout_plane, scale);
+  mlp_bwd_f16_kernel<HID, ACT, EH><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles,
+                                                          dout_plane, scale);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
 
 int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                        const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                       hipStream_t st, int64_t dout_plane, float scale) {
+                       hipStream_t st, int64_t dout_plane, float scale, bool enc_half) {
   if (n == 0) return IMMOCO_OK;
-  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+  IMMOCO_REQUIRE(enc_half || ((ps % 2) == 0 && (ls % 2) == 0), "mlp input strides must be even");
   IMMOCO_REQUIRE(scale > 0.f, "mlp_bwd_half: loss scale must be positive");
-  if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH)
-    return launch_bwd_f16_t<64, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale);
-  if (cfg.n_hidden == 64)
-    return launch_bwd_f16_t<64, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale);
-  if (cfg.activation == IMMOCO_ACT_TANH)
-    return launch_bwd_f16_t<256, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale);
-  return launch_bwd_f16_t<256, IMMOCO_ACT_RELU>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale);
+#define IMMOCO_BWD(H, A)                                                                                          \
+  return enc_half ? launch_bwd_f16_t<H, A, true>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale) \
+                  : launch_bwd_f16_t<H, A, false>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale)
+  if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH) IMMOCO_BWD(64, IMMOCO_ACT_TANH);
+  if (cfg.n_hidden == 64) IMMOCO_BWD(64, IMMOCO_ACT_RELU);
+  if (cfg.activation == IMMOCO_ACT_TANH) IMMOCO_BWD(256, IMMOCO_ACT_TANH);
+  IMMOCO_BWD(256, IMMOCO_ACT_RELU);
+#undef IMMOCO_BWD
 }
 
 }  // namespace immoco
@@ -444,7 +477,7 @@ extern "C" int immoco_mlp_fwd_half(const immoco_mlp_cfg* cfg, const float* in, i
   int rc = check_mlp_cfg(cfg);
   if (rc) return rc;
   IMMOCO_REQUIRE(n >= 0 && (n == 0 || (in && w1 && w2 && out)), "mlp_fwd_half: NULL buffer");
-  return launch_mlp_fwd_f16(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, out, as_stream(stream));
+  return launch_mlp_fwd_f16(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, out, as_stream(stream), false);
 }
 
 extern "C" int immoco_mlp_bwd_half(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
@@ -455,5 +488,5 @@ extern "C" int immoco_mlp_bwd_half(const immoco_mlp_cfg* cfg, const float* in, i
   if (rc) return rc;
   IMMOCO_REQUIRE(n >= 0 && (n == 0 || (in && w1 && w2 && dout && din && dw1 && dw2)), "mlp_bwd_half: NULL buffer");
   return launch_mlp_bwd_f16(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, dout, din, dw1, dw2,
-                            as_stream(stream), 0, loss_scale);
+                            as_stream(stream), 0, loss_scale, false);
 }

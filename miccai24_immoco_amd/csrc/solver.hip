@@ -129,6 +129,12 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   float* g_w2m = g_w1m + (int64_t)c.motion_mlp.n_hidden * c.motion_mlp.n_in;
   float* g_tabm = s->grad_mot + s->n_w_mot;
   float* slot1 = s->fftbuf + 2 * P;
+  // cfg.mlp_fp16: the encodings (and dL/d enc, scaled by tcnn's loss scale) live as packed halves, one 4-byte word
+  // per (point, level), like tiny-cuda-nn's fp16 encoding output / dL/dinput: half the bytes for the two MLP
+  // kernels and 4-byte gathers for the encode backward.  (The generic atomic scatter reads fp32: fp32 buffers then.)
+  const bool act16 = s->cfg.mlp_fp16 && !s->cfg.atomic_scatter;
+  const int64_t e_ps = act16 ? 1 : 2;                  // strides of the level-major encodings, in 4-byte words
+  const int64_t e_ls_m = act16 ? NP : 2 * NP, e_ls_i = act16 ? P : 2 * P;
 
   std::vector<Step> st;
   // The motion forward is captured FIRST: of the two root chains of the replayed graph, the one captured first starts
@@ -139,24 +145,25 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   if (nM > 0) {
     st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
                     if (s->cfg.table_fp16)
-                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, 2, 2 * NP, q);
-                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, 2, 2 * NP, q);
+                      return launch_hashgrid_fwd_half(s->lv_mot, lm, NP, s->shadow_mot, s->enc_mot, e_ps, e_ls_m, q, act16);
+                    return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, e_ps, e_ls_m, q, act16);
                   }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
                     if (s->cfg.mlp_fp16)
-                      return launch_mlp_fwd_f16(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
+                      return launch_mlp_fwd_f16(s->cfg.motion_mlp, s->enc_mot, e_ps, e_ls_m, NP, w1m, w2m, s->o_mot, q, act16);
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
                   }, 1});
   }
   };
   auto push_image_fwd = [&] {
   st.push_back({"image_encode_fwd", [=](hipStream_t q) {
-                  if (s->cfg.table_fp16) return launch_hashgrid_fwd_half(s->lv_img, li, P, s->shadow_img, s->enc_img, 2, 2 * P, q);
-                  return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, 2, 2 * P, q);
+                  if (s->cfg.table_fp16)
+                    return launch_hashgrid_fwd_half(s->lv_img, li, P, s->shadow_img, s->enc_img, e_ps, e_ls_i, q, act16);
+                  return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, e_ps, e_ls_i, q, act16);
                 }, 2});
   st.push_back({"image_mlp_fwd", [=](hipStream_t q) {
                   if (s->cfg.mlp_fp16)
-                    return launch_mlp_fwd_f16(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
+                    return launch_mlp_fwd_f16(s->cfg.image_mlp, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->image, q, act16);
                   return launch_mlp_fwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
                 }, 2});
   st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }, 2});
@@ -204,32 +211,55 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   }});
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
                     if (s->cfg.mlp_fp16)
-                      return launch_mlp_bwd_f16(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
-                                                s->enc_mot, g_w1m, g_w2m, q, 0, TCNN_LOSS_SCALE);
+                      return launch_mlp_bwd_f16(s->cfg.motion_mlp, s->enc_mot, e_ps, e_ls_m, NP, w1m, w2m, s->o_mot,
+                                                s->enc_mot, g_w1m, g_w2m, q, 0, TCNN_LOSS_SCALE, act16);
                     return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
                                           s->enc_mot, g_w1m, g_w2m, q);
                   }, fork_early ? 1 : 0});  // "late": before the fork, the image chain's MFMA-bound MLP backward
                         // then runs beside the gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
   }
+  // Second fork: which chain is captured (and therefore starts) first.  "motion" (default in fp32): the 448-register
+  // wide MLP backward must not take whole CUs ahead of the dominant gather (1.39 vs 1.35 ms, round 2).  "image": with
+  // fp16 MLPs the wide backward (59 KB of LDS, <= 256 registers, 41 us alone) fits BESIDE two encode-backward
+  // workgroups per CU - but only if its 256 workgroups are placed before the gather's 6000 fill every CU three deep
+  // (then it runs in the gather's tail: 453 us, and the image chain ends the iteration 48 us after the motion chain).
+  // A/B switch (environment, read once): IMMOCO_FORK2=image|motion.
+  static const int fork2_env = [] {
+    const char* e = getenv("IMMOCO_FORK2");
+    return !e ? -1 : (strcmp(e, "image") == 0 ? 1 : 0);
+  }();
+  const bool image_first2 = fork2_env >= 0 ? fork2_env == 1 : false;
+  auto push_motion_encode_bwd = [&] {
   if (nM > 0) {
     st.push_back({"motion_encode_bwd", [=](hipStream_t q) {
                     if (s->plan_mot)
-                      return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q);
+                      return launch_csr_bwd(s->plan_mot, s->enc_mot, g_tabm, s->mot_gstride, 1, q, act16,
+                                            1.f / TCNN_LOSS_SCALE);
                     return launch_hashgrid_bwd(s->lv_mot, nullptr, &lm, NP, s->enc_mot, 2, 2 * NP, g_tabm, q);
                   }, 1});
   }
+  };
+  auto push_image_mlp_bwd = [&] {
   // (The image chain's MFMA kernel starves beside the motion grid's encode backward - 0.53 ms instead of 0.14 in
   // the rocprofv3 stats - and slows that gather from 0.45 to 0.58 ms; run BEFORE the fork instead, alone, the
   // iteration takes 1.435 ms instead of 1.351: the overlap is still worth more than it costs.)
   st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
                   if (s->cfg.mlp_fp16)
-                    return launch_mlp_bwd_f16(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage,
-                                              s->enc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE);
+                    return launch_mlp_bwd_f16(s->cfg.image_mlp, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->dimage,
+                                              s->enc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16);
                   return launch_mlp_bwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
                                         g_w1i, g_w2i, q, /*planar dimage*/ P);
                 }, 2});
+  };
+  if (image_first2) {
+    push_image_mlp_bwd();
+    push_motion_encode_bwd();
+  } else {
+    push_motion_encode_bwd();
+    push_image_mlp_bwd();
+  }
   st.push_back({"image_encode_bwd", [=](hipStream_t q) {
-                  if (s->plan_img) return launch_csr_bwd(s->plan_img, s->enc_img, g_tabi, 0, 1, q);
+                  if (s->plan_img) return launch_csr_bwd(s->plan_img, s->enc_img, g_tabi, 0, 1, q, act16, 1.f / TCNN_LOSS_SCALE);
                   return launch_hashgrid_bwd(s->lv_img, nullptr, &li, P, s->enc_img, 2, 2 * P, g_tabi, q);
                 }, 2});
   // optimizer param-group order of the reference: motion first, then image (immoco.py:149-154)
@@ -499,7 +529,9 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   // point ranges of the motion grid's transposed index: as many as it takes to bring one level slice of dL/denc
   // (8 B per point) down to ~2 MB per XCD L2 (csr.hip): 320x320x10 -> 4, 640x640x20 -> 32; at most 8 of them run
   // in one launch, each into its own partial gradient table (summed by Adam), further ones in following launches
-  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W);
+  // (with cfg.mlp_fp16 dL/denc is stored as packed halves: half the bytes per point, half the parts - at 320x320x10
+  // 2 parts instead of 4: encode backward 0.386 -> 0.374 ms, motion Adam 0.069 -> 0.054 ms, iteration 1.042 -> 1.020)
+  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W, cfg->mlp_fp16 && !cfg->atomic_scatter ? 4 : 8);
   s->mot_parts = cfg->atomic_scatter ? 1 : (cfg->grad_parts > 0 ? cfg->grad_parts : auto_parts);
   s->mot_tables = std::min(s->mot_parts, 8);
   s->mot_gstride = (s->n_params_mot + 3) / 4 * 4;

@@ -378,17 +378,19 @@ class _MLPHalf(torch.autograd.Function):
     src/models/immoco.py:11-25,60-65: FullyFusedMLP / CutlassMLP are instantiated with `__half` network
     precision): every matrix-product operand is rounded to fp16 - the encoding, W1, the hidden activations, W2,
     and in the backward dL/dout * loss_scale (tcnn's torch binding: loss_scale = 128) and dL/dpre - every
-    product is accumulated in fp32 (tensor cores / MFMA), activations are evaluated in fp32.  Outputs, dL/denc
-    and the weight gradients leave in fp32 (tcnn narrows them to fp16 as well; this mode is never narrower than
-    tcnn).  The derivative of the activation is taken from the STORED fp16 activation, like tcnn's backward."""
+    product is accumulated in fp32 (tensor cores / MFMA), activations are evaluated in fp32.  Outputs and the
+    weight gradients leave in fp32 (tcnn narrows them to fp16 as well; this mode is never narrower than tcnn).
+    `denc_fp16`: dL/denc * loss_scale is rounded to fp16 before it is unscaled - what tcnn hands to its grid
+    backward, and what the solver stores between its MLP and encode backward kernels (the op-level C-ABI keeps
+    fp32 there).  The derivative of the activation is taken from the STORED fp16 activation, like tcnn's backward."""
 
     @staticmethod
-    def forward(ctx, enc, w1, w2, act, loss_scale):
+    def forward(ctx, enc, w1, w2, act, loss_scale, denc_fp16=False):
         e16, w1h, w2h = enc.half().float(), w1.half().float(), w2.half().float()
         pre = e16 @ w1h.t()
         h16 = (torch.relu(pre) if act == "relu" else torch.tanh(pre)).half().float()
         ctx.save_for_backward(e16, w1h, w2h, h16)
-        ctx.act, ctx.S = act, float(loss_scale)
+        ctx.act, ctx.S, ctx.denc_fp16 = act, float(loss_scale), bool(denc_fp16)
         return h16 @ w2h.t()
 
     @staticmethod
@@ -398,7 +400,10 @@ class _MLPHalf(torch.autograd.Function):
         d16 = (dout * S).half().float()
         dact = (h16 > 0).float() if ctx.act == "relu" else 1.0 - h16 * h16
         dp16 = ((d16 @ w2h) * dact).half().float()
-        return (dp16 @ w1h) / S, (dp16.t() @ e16) / S, (d16.t() @ h16) / S, None, None
+        denc = dp16 @ w1h
+        if ctx.denc_fp16:
+            denc = denc.half().float()
+        return denc / S, (dp16.t() @ e16) / S, (d16.t() @ h16) / S, None, None, None
 
 
 class OracleINR(torch.nn.Module):
@@ -408,11 +413,12 @@ class OracleINR(torch.nn.Module):
     first forward (the reference always passes the same grid)."""
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False,
-                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0):
+                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True):
         super().__init__()
         self.table_fp16 = table_fp16   # gather from an fp16 copy of the table (fp32 master, straight-through)
         self.mlp_fp16 = mlp_fp16       # fp16 MLP operands, fp32 accumulation (_MLPHalf): tcnn's network precision
         self.loss_scale = loss_scale
+        self.denc_fp16 = denc_fp16     # with mlp_fp16: dL/denc * loss_scale rounded to fp16 (the solver's layout)
         self.backend = backend         # "c": oracle/hashgrid_oracle.c; "torch": the torch expression + autograd
         self.bwd_order = bwd_order     # summation order of the C backward (HashGridPlan)
         self.geo = geometry_from_config(n_input_dims, encoding_config)
@@ -465,7 +471,7 @@ class OracleINR(torch.nn.Module):
         if perm is not None:
             enc = enc[perm]
         if self.mlp_fp16:
-            out = _MLPHalf.apply(enc, w1, w2, self.mlp.activation, self.loss_scale)
+            out = _MLPHalf.apply(enc, w1, w2, self.mlp.activation, self.loss_scale, self.denc_fp16)
         else:
             pre = enc @ w1.t()
             h = torch.relu(pre) if self.mlp.activation == "relu" else torch.tanh(pre)

@@ -187,7 +187,7 @@ def test_mlp_half_fwd_bwd_vs_oracle(env, which, n):
     w1 = (torch.randn(hid, 32, generator=g) * 0.2).requires_grad_(True)
     w2 = (torch.randn(pad, hid, generator=g) * 0.2).requires_grad_(True)
     dout = torch.randn(n, 2, generator=g) * 0.05
-    out = orc._MLPHalf.apply(x, w1, w2, act, 128.0)[:, :2]
+    out = orc._MLPHalf.apply(x, w1, w2, act, 128.0, False)[:, :2]
     (out * dout).sum().backward()
     xd, w1d, w2d, dd = dev(x.detach()), dev(w1.detach()), dev(w2.detach()), dev(dout)
     st = L.stream_ptr()

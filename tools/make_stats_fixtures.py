@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""tests/golden fixtures of the statistical parity tests from CPU-oracle runs made by tools/oracle_c2.py:
+
+    python tools/make_stats_fixtures.py /tmp/orc3
+
+  c2_oracle_200it_draws.npz        the reference script's own setting (iters = 200, /root/reference/src/test/
+                                   test_immoco.py:65-72) at 320x320 / 10 groups: per slice (1, 4, 9) the loss and the
+                                   PSNR of EVERY iteration of 8 draws (fp32 summation orders 0, 1, 2, 3, 5, 7, 11, 13 of
+                                   the hash-grid backward), plus a checksum of the input the draws were run on
+  c2_oracle_slice1_redraw1400.npz  the first 1400 iterations of the 3000-iteration solve of slice 1 with NEW summation
+                                   orders drawn before EVERY step (OracleIMMoCo.redraw): 6 draws, loss and PSNR of every
+                                   iteration
+"""
+import glob, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+src = sys.argv[1]
+out = {}
+for sl in (1, 4, 9):
+    fs = sorted(glob.glob(os.path.join(src, f"s{sl}_200_o*.npz")))
+    ds = [np.load(f) for f in fs]
+    ds = [d for d in ds if int(d["iters_done"]) == 200 and int(d["sched_iters"]) == 200 and int(d["redraw_seed"]) < 0]
+    if not ds:
+        continue
+    for d in ds:
+        assert int(d["slice_idx"]) == sl and np.array_equal(d["kspace"], ds[0]["kspace"]) and np.array_equal(d["lines"], ds[0]["lines"])
+    out[f"s{sl}_loss"] = np.array([d["loss"] for d in ds], dtype=np.float32)
+    out[f"s{sl}_psnr"] = np.array([d["psnr_all"] for d in ds], dtype=np.float32)
+    out[f"s{sl}_order"] = np.array([int(d["order"]) for d in ds], dtype=np.int32)
+    out[f"s{sl}_kspace_abs_sum"] = np.float64(np.abs(ds[0]["kspace"]).astype(np.float64).sum())
+    out[f"s{sl}_n_groups"] = np.int32(ds[0]["n_groups"])
+    p = out[f"s{sl}_psnr"]
+    print(f"slice {sl}: {len(ds)} draws, final PSNR {np.round(p[:, -1], 2)} mean {p[:, -1].mean():.3f} sd {p[:, -1].std(ddof=1):.3f}; "
+          f"median of last 21: {np.round(np.median(p[:, 179:], axis=1), 2)}")
+if out:
+    np.savez_compressed(os.path.join(OUT, "c2_oracle_200it_draws.npz"), **out)
+    print("c2_oracle_200it_draws.npz", os.path.getsize(os.path.join(OUT, "c2_oracle_200it_draws.npz")), "bytes")
+fs = sorted(glob.glob(os.path.join(src, "s1_rd1400_*.npz")))
+ds = [np.load(f) for f in fs]
+ds = [d for d in ds if int(d["iters_done"]) == 1400 and int(d["sched_iters"]) == 3000 and int(d["redraw_seed"]) >= 0]
+if ds:
+    np.savez_compressed(os.path.join(OUT, "c2_oracle_slice1_redraw1400.npz"),
+                        loss=np.array([d["loss"] for d in ds], dtype=np.float32),
+                        psnr=np.array([d["psnr_all"] for d in ds], dtype=np.float32),
+                        redraw_seed=np.array([int(d["redraw_seed"]) for d in ds], dtype=np.int32), slice_idx=np.int32(1))
+    p = np.array([d["psnr_all"] for d in ds])
+    print(f"redraw: {len(ds)} draws; PSNR@1399 {np.round(p[:, -1], 2)}; median(1350..1399) {np.round(np.median(p[:, 1350:], axis=1), 2)}; "
+          f"samples < 38 dB between 100 and 1399: {(p[:, 100:] < 38).mean():.3f}")
+    rec = np.load(os.path.join(OUT, "c2_oracle_slice1_3000it.npz"))
+    it = list(rec["oracle_psnr_iters"])
+    o = rec["oracle_psnr"]
+    print("fixed-order records: PSNR@1400", np.round(o[:, it.index(1400)], 2), "every-25 samples < 38 dB between 100 and 1500:",
+          float((o[:, it.index(100):it.index(1500) + 1] < 38).mean()))
+    print("redraw every-25 samples < 38 dB between 100 and 1375:", float((p[:, 100:1400:25] < 38).mean()),
+          " sd of PSNR@1375 across draws: redraw %.3f fixed %.3f" % (p[:, 1375].std(ddof=1), o[:, it.index(1375)].std(ddof=1)))
