@@ -223,17 +223,43 @@ def main():
         psnr_in = [crop_psnr(IFFT(tsl[j]["kspace"]).abs().cpu(), tsl[j]["gt"].abs().cpu()) for j in range(K * B)]
         psnr_delta = None
         if ref_rec is not None and K >= 1:
-            # HIP run-to-run spread of the same slice (outside the timed region): the trajectory is chaotic
-            # (24 runs: mean 34.94 dB, sd 1.75, profiles/r02_c2_end_psnr_24runs.txt - so eight runs here)
-            extra = [crop_psnr(solve(tsl[0])[0].abs().cpu(), tsl[0]["gt"].abs()) for _ in range(7)]
-            hip = [psnr[0]] + extra
-            om = sum(ref_rec["oracle_psnr_db"]) / len(ref_rec["oracle_psnr_db"])
-            psnr_delta = {"psnr_delta_db": round(sum(hip) / len(hip) - om, 3), "slice": "config C2, slice 1",
-                          "hip_psnr_db": [round(p, 3) for p in hip], "hip_timed_run_psnr_db": round(psnr[0], 3),
+            # HIP run-to-run spread of the same slice (outside the timed region).  The trajectory is chaotic: every run
+            # - HIP and oracle alike - goes through about one loss blow-up between iterations 1050 and 1460 and recovers
+            # within ~150 iterations (tools/diag_blowups.py), and PSNR oscillates with period 2 by +-1.5 dB, so single-run,
+            # single-iteration PSNR says little: seven extra runs are sampled at 1350 ... 1450 (every 25 iterations, the
+            # oracle records' grid; median per run = the lambda_GE > 0 checkpoint) and at the end, with standard errors.
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from _stats import hip_psnr_samples, summarize, delta_with_se
+            import numpy as np
+            rec = np.load(os.path.join(fx, "c2_oracle_slice1_3000it.npz"))
+            its = list(rec["oracle_psnr_iters"])
+            mid_it, end_it = [1350, 1375, 1400, 1425, 1450], [2900, 2925, 2950, 2975, 2999]
+            o_mid = np.median(rec["oracle_psnr"][:, [its.index(t) for t in mid_it]], axis=1)
+            o_end = np.median(rec["oracle_psnr"][:, [its.index(t) for t in end_it]], axis=1)
+            o_last = rec["oracle_psnr"][:, -1]
+            ksl = tsl[0]["kspace"]
+            kin1 = ksl / ksl.abs().max() * 16000
+            from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group as _m2c
+            h_mid, h_end, h_last = [], [], [psnr[0]]
+            for _ in range(7):
+                ps_, _l = hip_psnr_samples(the_solver(), kin1, _m2c(tsl[0]["masks"]), tsl[0]["gt"].abs().cpu(), 3000, mid_it + end_it)
+                h_mid.append(float(np.median([ps_[t] for t in mid_it])))
+                h_end.append(float(np.median([ps_[t] for t in end_it])))
+                h_last.append(ps_[2999])
+            d_mid, d_end, d_last = delta_with_se(h_mid, o_mid), delta_with_se(h_end, o_end), delta_with_se(h_last, o_last)
+            psnr_delta = {"psnr_delta_db": round(d_last[0], 3), "psnr_delta_se_db": round(d_last[1], 3),
+                          "slice": "config C2, slice 1", "n_hip_runs": len(h_last), "n_oracle_records": int(len(o_last)),
+                          "hip_psnr_db": [round(p, 3) for p in h_last], "hip_timed_run_psnr_db": round(psnr[0], 3),
                           "oracle_psnr_db": ref_rec["oracle_psnr_db"], "oracle_source": ref_rec["source"],
-                          "note": "mean over 8 HIP runs minus mean over the oracle records; single HIP runs have a standard "
-                                  "deviation of 1.75 dB once lambda_GE has underflowed to 0 at iteration 1500 (64 runs: mean "
-                                  "34.96 dB vs the six oracle records' 34.62, profiles/r02_c2_end_psnr_{24,40}runs.txt; DESIGN.md 2)"}
+                          "at_1400_window_median": {"delta_db": round(d_mid[0], 3), "se_db": round(d_mid[1], 3),
+                                                    "variance_ratio": round(d_mid[2], 2), "n_hip_runs": len(h_mid),
+                                                    "hip_db": [round(v, 2) for v in h_mid], "oracle_db": [round(float(v), 2) for v in o_mid],
+                                                    "what": "per run: median PSNR over iterations 1350, 1375, 1400, 1425, 1450 "
+                                                            "(lambda_GE = 1e-2 still)"},
+                          "end_window_median": {"delta_db": round(d_end[0], 3), "se_db": round(d_end[1], 3),
+                                                "variance_ratio": round(d_end[2], 2), "n_hip_runs": len(h_end)},
+                          "note": "HIP mean minus oracle-record mean with the standard error of that difference; 8 runs resolve "
+                                  "~0.5 dB, the suite's 32-run distribution tests (tests/test_gpu_ops.py) and DESIGN.md 2.2 resolve more"}
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
         solver = the_solver()
         sl = slices[0]
@@ -301,6 +327,7 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_measured_in_this_run": False,
             "kernel_ms": round(ms, 4), "kernel_ms_concurrent": round(ms_conc, 4),
             "kernel_algorithmic_bytes": ab[name],
             "note": "gather kernels are bound by the rate of divergent cache-line requests (rocprof: TA busy 94 %), "

@@ -279,10 +279,27 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
     }
     return e4[i];
   };
-  if ((uint32_t)wave < it.n_wc) {
+  // nt & 4: TIMING-ONLY ablation (wrong results): only HALF of the entry stream is loaded - what 4-byte entries
+  // would stream - and the missing entries are stand-ins made from the loaded ones with another point (same slot,
+  // another cache line), so that gathers and arithmetic stay what they are.  The upper bound of what a 4-byte entry
+  // format can gain BEFORE its decode work is added.
+  const bool half_stream = (nt & 4) != 0;
+  const uint32_t psz = (uint32_t)part_size;
+  auto fill = [&](size_t base) {
 #pragma unroll
-    for (int j = 0; j < EPT / 2; ++j) q[j] = ld((size_t)wave * (WAVE_CHUNK / 2) + j * 64 + lane);
-  }
+    for (int j = 0; j < EPT / 2; ++j) {
+      if (half_stream && j >= EPT / 4) {
+        uint4 v = q[j - EPT / 4];
+        const uint32_t a = v.x ^ (1u << (SLOT_BITS + 7)), b = v.z ^ (1u << (SLOT_BITS + 7));
+        v.x = (a >> SLOT_BITS) < psz ? a : v.x;
+        v.z = (b >> SLOT_BITS) < psz ? b : v.z;
+        q[j] = v;
+      } else {
+        q[j] = ld(base + j * 64 + lane);
+      }
+    }
+  };
+  if ((uint32_t)wave < it.n_wc) fill((size_t)wave * (WAVE_CHUNK / 2));
   auto store_run = [&](uint32_t unit, const float (&v)[NS]) {   // unit: slot (NS = 2) or slot pair (NS = 4)
     if (PAIR) *reinterpret_cast<float4*>(&accA[4 * unit]) = make_float4(v[0], v[1], v[2], v[3]);
     else *reinterpret_cast<float2*>(&accA[2 * unit]) = make_float2(v[0], v[1]);
@@ -301,10 +318,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(int64_t n_points, int64_t 
       key[2 * j + 1] = q[j].z;
       wt[2 * j + 1] = __uint_as_float(q[j].w);
     }
-    if (wc + 4 < it.n_wc) {  // prefetch this wave's next chunk
-#pragma unroll
-      for (int j = 0; j < EPT / 2; ++j) q[j] = ld((size_t)(wc + 4) * (WAVE_CHUNK / 2) + j * 64 + lane);
-    }
+    if (wc + 4 < it.n_wc) fill((size_t)(wc + 4) * (WAVE_CHUNK / 2));  // prefetch this wave's next chunk
     float2 g[EPT];
     if (DH) {
       __half2 gh[EPT];
@@ -694,7 +708,7 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
   // the default)
   static const int nt = [] {
     const char* e = getenv("IMMOCO_CSR_STREAM");
-    return (e && strcmp(e, "plain") == 0) ? 0 : (e && atoi(e) > 0 ? (atoi(e) & 3) : 3);
+    return (e && strcmp(e, "plain") == 0) ? 0 : (e && atoi(e) > 0 ? (atoi(e) & 7) : 3);   // 7 = 3 + the half-stream ablation
   }();
   // Three workgroups per CU instead of the four that 33 KB of LDS would allow (12 KB of unused dynamic LDS): fewer
   // (part, level) windows in flight per XCD L2.  Isolated kernel, 4 -> 3 per CU: 320x320x10 0.448 -> 0.429 ms (2 per

@@ -405,7 +405,8 @@ int run_steps(const std::vector<Step>& steps, hipStream_t q) {
 // fork/join execution of the branch annotations (works eagerly and under stream capture)
 // hook(step, stream, before): called right before / after a step is issued on its stream (cross-slice ordering)
 typedef std::function<int(const Step&, hipStream_t, bool)> StepHook;
-int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q, const StepHook* hook = nullptr);
+int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q, const StepHook* hook = nullptr,
+                     bool join_at_end = true);
 
 int ensure_sched(immoco_solver* s, int32_t iters) {
   if (iters <= s->sched_cap) return IMMOCO_OK;
@@ -445,7 +446,8 @@ int leave(immoco_solver* s, hipStream_t caller) {
 }  // namespace
 
 namespace {
-int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q, const StepHook* hook) {
+int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream_t q, const StepHook* hook,
+                     bool join_at_end) {
   bool forked = false;
   int ev = 0;
   for (const Step& st : steps) {
@@ -473,7 +475,7 @@ int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream
       s->marked = true;
     }
   }
-  if (forked) {
+  if (forked && join_at_end) {
     IMMOCO_CHECK_HIP(hipEventRecord(s->ev_fj[ev], s->side));
     IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, s->ev_fj[ev], 0));
   }
@@ -733,11 +735,30 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
   const std::vector<Step> first = arrange(all, pipelined ? Order::First : Order::Classic);
   const std::vector<Step> steady = pipelined ? arrange(all, Order::Steady) : first;
   auto run_list = [&](const std::vector<Step>& l) { return s->cfg.serial_chains ? run_steps(l, q) : run_steps_forked(s, l, q); };
+  // A/B switch IMMOCO_CHAIN_ITERS=1 (environment, read once; OFF by default - measured slower): inside a graph of
+  // several iterations the image chain does not join the motion chain at the END of an iteration: the iteration
+  // counter's tick moves to the side stream (behind the image Adam, and behind the motion Adam by an event), the
+  // main stream goes from the motion Adam of iteration k straight into the motion forward of k + 1 and the side stream
+  // from the tick into the image forward of k + 1; the chains only meet where data does.  That takes the image chain's
+  // ~50 us tail and the join / tick / fork gaps off the critical path - and puts the tail (image encode backward,
+  // image Adam) BESIDE the next motion encode forward, whose 4 MB level slices then fall out of the XCD L2s
+  // (DESIGN.md 4.1): 1.254 -> 1.371 ms per iteration in fp32, 1.029 -> 1.070 with fp16 MLPs.
+  static const bool chain_iters = [] { const char* e = getenv("IMMOCO_CHAIN_ITERS"); return e && atoi(e) != 0; }();
+  std::vector<Step> chained = first;
+  for (Step& x : chained)
+    if (strcmp(x.name, "tick") == 0) x.branch = 2;
+  const StepHook tick_hook([s](const Step& st, hipStream_t sq, bool before) -> int {
+    if (strcmp(st.name, "adam_motion") == 0 && !before) IMMOCO_CHECK_HIP(hipEventRecord(s->ev_fj[7], sq));
+    if (strcmp(st.name, "tick") == 0 && before) IMMOCO_CHECK_HIP(hipStreamWaitEvent(sq, s->ev_fj[7], 0));
+    return IMMOCO_OK;
+  });
   auto capture = [&](const std::vector<Step>& l, hipGraphExec_t* out, int reps) {
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal) != hipSuccess) return;
     int r = IMMOCO_OK;
-    for (int k = 0; k < reps && r == IMMOCO_OK; ++k) r = run_list(l);
+    const bool chain = chain_iters && reps > 1 && !pipelined && !s->cfg.serial_chains && s->cfg.nM > 0;
+    for (int k = 0; k < reps && r == IMMOCO_OK; ++k)
+      r = chain ? run_steps_forked(s, chained, q, &tick_hook, k == reps - 1) : run_list(l);
     const hipError_t e2 = hipStreamEndCapture(q, &graph);
     if (r == IMMOCO_OK && e2 == hipSuccess && graph)
       if (hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;

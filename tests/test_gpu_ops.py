@@ -1303,6 +1303,66 @@ def test_config2_distribution_vs_oracle_draws(env, golden):
     assert plo <= max(psnrs) <= phi + 1.0 and float(np.median(psnrs)) >= 31.0, (psnrs, op[:, -1])
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16mlp"])
+@pytest.mark.parametrize("slice_idx", [1, 4, 9])
+def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, golden, slice_idx, mode):
+    """Parity at the reference's OWN operating point: `iters=200`, 320x320, 10 groups
+    (/root/reference/src/test/test_immoco.py:65-72; lambda_GE is halved 95 times and never reaches 0) on three slices
+    (1, 4 and 9 = the 22.99 dB slice of round 2's bench line), 32 HIP solves per slice against 8 CPU-oracle draws
+    (tests/golden/c2_oracle_200it_draws.npz: fp32 summation orders 0, 1, 2, 3, 5, 7, 11, 13; loss and PSNR of every
+    iteration).  PSNR oscillates with period 2 (Adam at lr 1e-2: +-1.5 dB late in a 3000-iteration solve, less here),
+    so the per-run statistic is the MEDIAN over the last 21 iterations; the final forward (what the reference returns)
+    is compared as well.  Assertions: the standard error of the HIP-minus-oracle difference resolves 0.35 dB, the
+    difference is within 3 of its standard errors (a 2-s.e. gate over six parametrisations would fail one run in
+    four by chance alone; the measured differences are in DESIGN.md 2.2), and HIP runs do not spread more than 3x
+    the oracle draws' variance (+ a 0.1 dB floor, the draws of a slice can agree to 0.05 dB).  `f16mlp` is
+    immoco_solver_cfg.mlp_fp16 (tiny-cuda-nn's network precision), held to the SAME fp32 oracle draws: the mode is
+    only a candidate for the headline if it is indistinguishable here."""
+    pkg, L, orc = env
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stats import hip_psnr_samples, summarize, delta_with_se
+    from oracle import synth_cpu
+    from miccai24_immoco_amd import synth
+    from miccai24_immoco_amd.models.immoco import get_solver
+    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    g = golden("c2_oracle_200it_draws")
+    if f"s{slice_idx}_psnr" not in g:
+        pytest.skip(f"no oracle draws for slice {slice_idx} in the fixture")
+    op, ol = g[f"s{slice_idx}_psnr"].astype(np.float64), g[f"s{slice_idx}_loss"].astype(np.float64)
+    assert op.shape[0] >= 6 and op.shape[1] == 200
+    s_ = synth_cpu.make_slice(320, 320, 10, slice_idx)          # the draws' input, regenerated and checked
+    ref_sum = float(g[f"s{slice_idx}_kspace_abs_sum"])
+    assert abs(float(s_["kspace"].abs().double().sum()) - ref_sum) <= 1e-6 * ref_sum
+    k, lines = s_["kspace"].cuda(), s_["lines"].cuda()
+    masks = pkg.extract_movement_groups(lines, make_list=True)
+    assert masks.shape[0] == int(g[f"s{slice_idx}_n_groups"])
+    gt = synth.phantom(320, 320, 1000 + slice_idx).abs()
+    sol = get_solver(torch.device("cuda", 0), 320, 320, int(masks.shape[0]), mlp_fp16=(mode == "f16mlp"))
+    kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
+    samples = list(range(179, 200))
+    h_med, h_fin, h_loss = [], [], []
+    for _ in range(32):
+        ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, samples)
+        h_med.append(float(np.median([ps[t] for t in samples])))
+        h_fin.append(ps[199])
+        h_loss.append(float(np.median(loss[179:200])))
+        assert abs(loss[0] - ol[0, 0]) <= (1e-3 if mode == "f16mlp" else 5e-5) * ol[0, 0]     # identical start
+    o_med, o_fin, o_loss = np.median(op[:, 179:200], axis=1), op[:, 199], np.median(ol[:, 179:200], axis=1)
+    d_med, d_fin = delta_with_se(h_med, o_med), delta_with_se(h_fin, o_fin)
+    print(f"slice {slice_idx} {mode}: median-of-last-21 PSNR hip %.3f (sd %.3f) oracle %.3f (sd %.3f) delta %.3f +- %.3f; "
+          f"final forward hip %.3f oracle %.3f delta %.3f +- %.3f; windowed loss hip %.4f (sd %.4f) oracle %.4f (sd %.4f)"
+          % (*summarize(h_med)[:2], *summarize(o_med)[:2], d_med[0], d_med[1], summarize(h_fin)[0], summarize(o_fin)[0],
+             d_fin[0], d_fin[1], *summarize(h_loss)[:2], *summarize(o_loss)[:2]))
+    for name, (delta, se, _), hv, ov in (("median21", d_med, h_med, o_med), ("final", d_fin, h_fin, o_fin)):
+        assert se <= 0.35, (name, se)
+        assert abs(delta) <= 3.0 * se + 0.05, (name, delta, se)
+        assert np.var(hv, ddof=1) <= 3.0 * np.var(ov, ddof=1) + 0.1 ** 2 * 3, (name, np.std(hv, ddof=1), np.std(ov, ddof=1))
+    # the objective itself: windowed loss within 3 standard errors (relative floor 2 %)
+    dl = delta_with_se(h_loss, o_loss)
+    assert abs(dl[0]) <= 3.0 * dl[1] + 0.02 * float(np.mean(o_loss)), (dl, h_loss, o_loss)
+
+
 def test_config2_3000_iterations_vs_cpu_oracle_records(env, golden):
     """The metric's own configuration end to end: 320x320, 10 groups, 3000 iterations, slice 1, against the
     recorded full CPU-oracle runs (tests/golden/c2_oracle_slice1_3000it.npz) and, up to iteration 400, the band
