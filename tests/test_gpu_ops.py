@@ -704,20 +704,26 @@ def test_teacher_forced_lambda_zero_phase_96(env):
         assert r["upd_max"] <= 1e-3 * 1e-2 and r["frac_update_off_by_1e3_lr"] == 0.0 and r["upd_rel_l2"] <= 5e-3, (name, r)
 
 
-def test_teacher_forced_state_c2_shape(env):
-    """The same at the metric's shape (320x320, 10 groups; 3000-iteration schedule), K = 5."""
+@pytest.mark.parametrize("K", [5, 200])
+def test_teacher_forced_state_c2_shape(env, K):
+    """The same at the metric's shape (320x320, 10 groups; 3000-iteration schedule): K = 5, and K = 200 - a late
+    state handed over after 200 live oracle iterations (~3 minutes of CPU on the GPU box)."""
     pkg, L, orc = env
     from oracle import synth_cpu
     s = synth_cpu.make_slice(320, 320, 10, 1)
     masks = orc.extract_movement_groups(s["lines"], make_list=True)
-    import os
-    K = int(os.environ.get("IMMOCO_TF_K", "5"))       # diagnostic: IMMOCO_TF_K=200 hands over a late state (minutes of CPU)
+    K = int(os.environ.get("IMMOCO_TF_K", str(K)))       # diagnostic override
     rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, K)
-    # measured: gradient rel. L2 6e-7 (image) / 7e-6 (motion), largest update difference 4.0e-6 = 4e-4 * lr
+    # measured, K = 5: gradient rel. L2 6e-7 (image) / 7e-6 (motion), largest update difference 4.0e-6 = 4e-4 * lr;
+    # K = 200: 2.7e-6 / 1.8e-5, update difference 2.5e-5 on 10 of 9.45 M entries (Adam turns a cancelling-sum gradient
+    # into a +-lr step: a handful of entries may differ by a few 1e-3 * lr there)
     for name in ("img", "mot"):
         r = rep[name]
         assert r["grad_rel_l2"] <= 1e-4 and r["grad_max_abs_over_max"] <= 1e-4, (name, r)
-        assert r["upd_max"] <= 1e-3 * 1e-2 and r["frac_update_off_by_1e3_lr"] == 0.0, (name, r)
+        if K <= 5:
+            assert r["upd_max"] <= 1e-3 * 1e-2 and r["frac_update_off_by_1e3_lr"] == 0.0, (name, r)
+        else:
+            assert r["upd_max"] <= 1e-2 * 1e-2 and r["frac_update_off_by_1e3_lr"] <= 1e-5, (name, r)
 
 
 def test_config1_workload_vs_live_oracle(env):

@@ -180,3 +180,61 @@ def test_c_encode_matches_torch_expression():
     t1 = torch.zeros(geo.n_entries, 2, requires_grad=True)
     (plan.encode_c(t1) * denc).sum().backward()
     assert (t1.grad - t0.grad).abs().max() <= 2e-5 * t0.grad.abs().max()
+
+
+def test_redraw_mode_is_the_same_function_in_another_summation_order():
+    """OracleIMMoCo.redraw (round 3: new fp32 summation orders before EVERY step - hash-grid backward block order, MLP
+    batch row order, motion-group order; the per-step analogue of tiny-cuda-nn's nondeterministic atomics): the
+    forward is bit-identical, the gradients agree to summation accuracy and are NOT bit-identical."""
+    import torch.nn.functional as F
+    from oracle import synth_cpu
+    s = synth_cpu.make_slice(64, 64, 3, 5)
+    masks = orc.extract_movement_groups(s["lines"], make_list=True)
+    model = orc.OracleIMMoCo(masks)
+    k = s["kspace"]
+    kin = k.div(k.abs().max()).mul(16000)
+
+    def grads():
+        model.zero_grad()
+        kf, ip = model()
+        loss = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(kin)) + orc.gradient_entropy_loss(ip) * 1e-2
+        loss.backward()
+        return float(loss), ip.detach().clone(), model.image_inr.params.grad.clone(), model.motion_inr.params.grad.clone()
+
+    l0, i0, gi0, gm0 = grads()
+    model.redraw(np.random.default_rng(3))
+    l1, i1, gi1, gm1 = grads()
+    assert torch.equal(i0, i1) and abs(l0 - l1) <= 1e-6 * abs(l0)
+    for a, b in ((gi0, gi1), (gm0, gm1)):
+        rel = float((a - b).norm() / a.norm())
+        assert 0.0 < rel <= 1e-5, rel
+
+
+def test_mlp_fp16_mode_rounds_what_tcnn_rounds():
+    """OracleINR(mlp_fp16=True) (_MLPHalf): fp16 operands, fp32 accumulation, loss scale 128; with denc_fp16 the
+    scaled dL/denc is rounded to fp16 as well.  Close to, not equal to, the fp32 network; the loss scale itself
+    changes nothing but the rounding (a power of two)."""
+    torch.manual_seed(0)
+    x = torch.rand(700, 3) * 2 - 1
+    kw = dict(seed=3)
+    a = orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, **kw)
+    b = orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, mlp_fp16=True, **kw)
+    c = orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, mlp_fp16=True, denc_fp16=False, **kw)
+    with torch.no_grad():
+        a.params[a.mlp.n_params:] *= 1e3           # features of order 0.1 instead of 1e-4
+        b.params.copy_(a.params)
+        c.params.copy_(a.params)
+    g = torch.randn(700, 2)
+    outs = []
+    for m in (a, b, c):
+        o = m(x)
+        o.backward(g)
+        outs.append((o.detach(), m.params.grad.clone()))
+    assert torch.equal(outs[1][0], outs[2][0])                         # same forward
+    d_out = float((outs[0][0] - outs[1][0]).norm() / outs[0][0].norm())
+    d_g = float((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm())
+    assert 1e-5 < d_out < 5e-3 and 1e-5 < d_g < 5e-3, (d_out, d_g)
+    nw = a.mlp.n_params
+    assert torch.equal(outs[1][1][:nw], outs[2][1][:nw])              # weight gradients do not see the denc rounding
+    d_t = float((outs[1][1][nw:] - outs[2][1][nw:]).norm() / outs[2][1][nw:].norm())
+    assert 0.0 < d_t < 2e-3, d_t                                       # table gradients do (2^-11 per contribution)
