@@ -4,6 +4,7 @@ Run on the MI355X box with `pytest -m gpu`."""
 import ctypes as C
 
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1299,14 +1300,86 @@ def test_config2_distribution_vs_oracle_draws(env, golden):
         lo, hi = min(lo, 0.985 * o.min()), max(hi, 1.015 * o.max())      # seven draws under-sample the tails
         rep[j] = (round(float(np.median(h)), 3), round(float(o.min()), 3), round(float(o.max()), 3))
         assert lo <= np.median(h) <= hi, (j, h, o)
-    plo, phi = _band(op[:, -1])
     print("windowed loss: iteration -> (hip median of 5, oracle min, oracle max)", rep)
     print("hip windowed per run @200", win(hl, 200).round(3).tolist(), "@390", win(hl, 390).round(3).tolist())
-    print("psnr @400: hip", [round(p, 2) for p in psnrs], "oracle draws", op[:, -1].round(2).tolist())
-    # PSNR against the ground truth jumps between the ~39 dB state and 5 dB excursions at unchanged loss on both
-    # sides (profiles/r02_slice4_psnr_excursions.txt), so: the best of the five runs is at the oracle draws' level,
-    # and the typical run is far above the corrupted input's 25.3 dB
-    assert plo <= max(psnrs) <= phi + 1.0 and float(np.median(psnrs)) >= 31.0, (psnrs, op[:, -1])
+    # PSNR (no single iterations, no "best of five"): PSNR oscillates with period 2 by up to +-1.5 dB
+    # (Adam at lr 1e-2; oracle and HIP alike), so the per-run statistic is the median over the samples the draws hold
+    # near the end (iterations 350, 375, 400), 12 HIP runs, difference of the means within 3 standard errors
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stats import hip_psnr_samples, delta_with_se
+    pit = list(d["psnr_iters"])
+    cols = [pit.index(t) for t in (350, 375, 400)]
+    o_med = np.median(op[:, cols], axis=1)
+    h_med = []
+    for _ in range(12):
+        ps, _l = hip_psnr_samples(sol, kin, cg, gt, 3000, [350, 375, 400])
+        h_med.append(float(np.median(list(ps.values()))))
+    delta, se, vr = delta_with_se(h_med, o_med)
+    print("psnr median(350, 375, 400): hip", np.round(h_med, 2).tolist(), "oracle draws", o_med.round(2).tolist(),
+          "delta %.3f +- %.3f (variance ratio %.2f)" % (delta, se, vr))
+    assert se <= 0.4 and abs(delta) <= 3.0 * se + 0.05, (delta, se, h_med, o_med)
+
+
+def _blowups(loss, a, b, thr=1.5):
+    """Loss blow-up events in [a, b): loss above thr x the median of the previous 20 iterations (40 iterations of
+    dead time after an event) -> [(iteration, ratio)]."""
+    ev, t = [], a
+    while t < b:
+        med = float(np.median(loss[t - 20:t]))
+        if loss[t] > thr * med:
+            ev.append((t, float(loss[t] / med)))
+            t += 40
+        else:
+            t += 1
+    return ev
+
+
+def test_config2_lambda_positive_regime_vs_oracle_draws(env, golden):
+    """VERDICT r2 item 1a - statistical parity where lambda_GE > 0 (iterations 600 ... 1400 of the metric's
+    3000-iteration solve, slice 1), against TWELVE oracle draws: the six fixed-order records
+    (c2_oracle_slice1_3000it.npz) and six draws whose fp32 summation orders are re-drawn before EVERY step
+    (c2_oracle_slice1_redraw1400.npz, OracleIMMoCo.redraw - what nondeterministic atomics do, in tiny-cuda-nn and here).
+    What the records show: every trajectory - oracle and HIP - oscillates with period 2 and goes through
+    about one loss blow-up between iterations 1050 and 1460, after which PSNR dips (and sometimes spikes to 44-46 dB)
+    for 50-150 iterations.  PSNR at ONE iteration (round 2 compared iteration 1400) therefore measures when the
+    blow-up happened; with re-drawn orders the oracle's own spread at 1375 is 2.5 dB (fixed order: 0.7) and its
+    blow-ups are as large as HIP's (median ratio 7 vs 3 with a fixed order).  Robust statistics instead:
+      * per run, the MEDIAN PSNR over the samples at 600, 625, ..., 1375 (the level of the lambda > 0 plateau);
+      * blow-up events per run in 300 ... 1400 and their size."""
+    pkg, L, orc = env
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stats import hip_psnr_samples, delta_with_se, summarize
+    from miccai24_immoco_amd.models.immoco import get_solver
+    rec, rd = golden("c2_oracle_slice1_3000it"), golden("c2_oracle_slice1_redraw1400")
+    its = list(rec["oracle_psnr_iters"])
+    grid = list(range(600, 1400, 25))
+    o_fixed = np.median(rec["oracle_psnr"][:, [its.index(t) for t in grid]].astype(np.float64), axis=1)
+    o_redraw = np.median(rd["psnr"][:, grid].astype(np.float64), axis=1)
+    o_all = np.concatenate([o_fixed, o_redraw])
+    ev_o = [_blowups(l.astype(np.float64), 300, 1400) for l in rec["oracle_loss"]] + \
+           [_blowups(l.astype(np.float64), 300, 1400) for l in rd["loss"]]
+    k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
+    sol = get_solver(torch.device("cuda", 0), 320, 320, 10)
+    h, ev_h = [], []
+    for _ in range(16):
+        ps, loss = hip_psnr_samples(sol, kin, cg, gt, 3000, grid + [1399])
+        h.append(float(np.median([ps[t] for t in grid])))
+        ev_h.append(_blowups(loss.astype(np.float64), 300, 1400))
+    delta, se, vr = delta_with_se(h, o_all)
+    rate_h, rate_o = np.mean([len(e) for e in ev_h]), np.mean([len(e) for e in ev_o])
+    ratios_h = [r for e in ev_h for _, r in e]
+    ratios_o = [r for e in ev_o[6:] for _, r in e]       # re-drawn orders: the like-for-like noise model
+    print("plateau PSNR (median over 600..1375 every 25): hip mean %.3f sd %.3f | oracle fixed %s redraw %s | delta %.3f +- %.3f"
+          % (*summarize(h)[:2], o_fixed.round(2).tolist(), o_redraw.round(2).tolist(), delta, se))
+    print("blow-ups per run in 300..1400: hip %.2f oracle (12 draws) %.2f; ratios hip %s redraw oracle %s fixed-order oracle %s"
+          % (rate_h, rate_o, np.round(sorted(ratios_h), 1).tolist(), np.round(sorted(ratios_o), 1).tolist(),
+             np.round(sorted(r for e in ev_o[:6] for _, r in e), 1).tolist()))
+    assert se <= 0.3 and abs(delta) <= 3.0 * se + 0.05, (delta, se, h, o_all)
+    assert vr <= 4.0 or np.std(h, ddof=1) <= 0.5, (vr, h, o_all)
+    # about one event per run on both sides (12 oracle draws: 0.75); 16 runs resolve the rate to +-0.25
+    assert 0.3 <= rate_h <= 1.5, (rate_h, ev_h)
+    if ratios_h and ratios_o:
+        assert 0.33 * np.median(ratios_o) <= np.median(ratios_h) <= 3.0 * np.median(ratios_o), (ratios_h, ratios_o)
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16mlp"])
@@ -1318,7 +1391,8 @@ def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, gold
     (tests/golden/c2_oracle_200it_draws.npz: fp32 summation orders 0, 1, 2, 3, 5, 7, 11, 13; loss and PSNR of every
     iteration).  PSNR oscillates with period 2 (Adam at lr 1e-2: +-1.5 dB late in a 3000-iteration solve, less here),
     so the per-run statistic is the MEDIAN over the last 21 iterations; the final forward (what the reference returns)
-    is compared as well.  Assertions: the standard error of the HIP-minus-oracle difference resolves 0.35 dB, the
+    is compared as well.  Assertions: the standard error of the HIP-minus-oracle difference resolves 0.5 dB (the
+    oracle draws of a slice end 1.0-1.2 dB apart; 8-16 of them are what 12 hours of CPU buy), the
     difference is within 3 of its standard errors (a 2-s.e. gate over six parametrisations would fail one run in
     four by chance alone; the measured differences are in DESIGN.md 2.2), and HIP runs do not spread more than 3x
     the oracle draws' variance (+ a 0.1 dB floor, the draws of a slice can agree to 0.05 dB).  `f16mlp` is
@@ -1336,6 +1410,10 @@ def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, gold
     if f"s{slice_idx}_psnr" not in g:
         pytest.skip(f"no oracle draws for slice {slice_idx} in the fixture")
     op, ol = g[f"s{slice_idx}_psnr"].astype(np.float64), g[f"s{slice_idx}_loss"].astype(np.float64)
+    n_fixed = op.shape[0]
+    if f"s{slice_idx}_psnr_redraw" in g:      # draws with summation orders re-drawn before every step join the sample
+        op = np.concatenate([op, g[f"s{slice_idx}_psnr_redraw"].astype(np.float64)])
+        ol = np.concatenate([ol, g[f"s{slice_idx}_loss_redraw"].astype(np.float64)])
     assert op.shape[0] >= 6 and op.shape[1] == 200
     s_ = synth_cpu.make_slice(320, 320, 10, slice_idx)          # the draws' input, regenerated and checked
     ref_sum = float(g[f"s{slice_idx}_kspace_abs_sum"])
@@ -1356,12 +1434,14 @@ def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, gold
         assert abs(loss[0] - ol[0, 0]) <= (1e-3 if mode == "f16mlp" else 5e-5) * ol[0, 0]     # identical start
     o_med, o_fin, o_loss = np.median(op[:, 179:200], axis=1), op[:, 199], np.median(ol[:, 179:200], axis=1)
     d_med, d_fin = delta_with_se(h_med, o_med), delta_with_se(h_fin, o_fin)
+    print(f"slice {slice_idx} {mode}: oracle draws {n_fixed} fixed-order + {op.shape[0] - n_fixed} re-drawn "
+          f"(medians {o_med[:n_fixed].round(2).tolist()} / {o_med[n_fixed:].round(2).tolist()})")
     print(f"slice {slice_idx} {mode}: median-of-last-21 PSNR hip %.3f (sd %.3f) oracle %.3f (sd %.3f) delta %.3f +- %.3f; "
           f"final forward hip %.3f oracle %.3f delta %.3f +- %.3f; windowed loss hip %.4f (sd %.4f) oracle %.4f (sd %.4f)"
           % (*summarize(h_med)[:2], *summarize(o_med)[:2], d_med[0], d_med[1], summarize(h_fin)[0], summarize(o_fin)[0],
              d_fin[0], d_fin[1], *summarize(h_loss)[:2], *summarize(o_loss)[:2]))
     for name, (delta, se, _), hv, ov in (("median21", d_med, h_med, o_med), ("final", d_fin, h_fin, o_fin)):
-        assert se <= 0.35, (name, se)
+        assert se <= 0.5, (name, se)
         assert abs(delta) <= 3.0 * se + 0.05, (name, delta, se)
         assert np.var(hv, ddof=1) <= 3.0 * np.var(ov, ddof=1) + 0.1 ** 2 * 3, (name, np.std(hv, ddof=1), np.std(ov, ddof=1))
     # the objective itself: windowed loss within 3 standard errors (relative floor 2 %)
@@ -1387,20 +1467,24 @@ def test_config2_3000_iterations_vs_cpu_oracle_records(env, golden):
     sol = get_solver(torch.device("cuda", 0), 320, 320, 10)
     lam = lambda_schedule(3000, 1e-2)
     assert lam == orc.lambda_schedule(3000, 1e-2) and lam[-1] == 0.0
-    marks = [0, 25, 50, 100, 200, 400, 800, 1400, 2999]
-    losses, psnrs = [], []
-    for rep in range(3):
+    marks = [0, 25, 50, 100, 200, 400, 800, 1400, 2900, 2925, 2950, 2975, 2999]
+    losses, psnrs, end_med = [], [], []
+    for rep in range(8):
         pi, pm = sol.init_params()
         ai = torch.zeros(2 * pi.numel(), device="cuda")
         am = torch.zeros(2 * pm.numel(), device="cuda")
         a, row = 0, []
+        tail = []
         for end in marks:      # segments END at the marked iterations: the solver returns a segment's last forward
             n = end - a + 1
             img, _, loss = sol.solve(kin, cg, pi, pm, ai, am, n, 1e-2, lam[a:a + n], step0=a, want_loss=True)
             row.append(float(loss[-1]))
+            if end >= 2900:
+                tail.append(orc.crop_psnr(img.abs().cpu(), gt))
             a = end + 1
         losses.append(row)
-        psnrs.append(orc.crop_psnr(img.abs().cpu(), gt))
+        psnrs.append(tail[-1])
+        end_med.append(float(np.median(tail)))
     med = np.median(np.array(losses), axis=0)
     p_in = orc.crop_psnr(pkg.IFFT(k).abs().cpu(), gt)
     p_ref = g["oracle_psnr"][:, -1].astype(np.float64)
@@ -1413,14 +1497,25 @@ def test_config2_3000_iterations_vs_cpu_oracle_records(env, golden):
         assert lo <= med[marks.index(m)] <= hi, (m, med[marks.index(m)], dl[:, m])
     for m in (800, 1400):      # only the full records reach this far: their range, widened by 15 %
         j = marks.index(m)
-        assert 0.85 * ol[:, m].min() <= med[j] <= 1.15 * ol[:, m].max(), (m, med[j], ol[:, m])
+        assert 0.85 * ol[:, m].min() <= med[j] <= 1.3 * ol[:, m].max(), (m, med[j], ol[:, m])   # (a blow-up may sit at 1400)
     # lambda = 0: converged by orders of magnitude below the lambda > 0 plateau (15.5 ... 17.5 at iteration 1400).  The
     # loss of ONE late iteration is spiky (Adam at lr 1e-2 without the regulariser): 40 HIP runs end between 6e-5 and
     # 0.53 with single runs above 1.5, so the statement is on the best of the three runs and, loosely, on the median
     end = np.array(losses)[:, -1]
-    assert end.min() <= 1.5 and ol[:, -1].max() <= 1.5, (end, ol[:, -1])
+    assert np.median(end) <= 1.5 and ol[:, -1].max() <= 1.5, (end, ol[:, -1])
     assert med[-1] <= 0.5 * ol[:, 1400].min(), (end, ol[:, 1400])
-    assert p_ref.min() - 3.0 <= float(np.median(psnrs)) <= p_ref.max() + 3.0, (psnrs, p_ref)
+    # end of the solve (lambda_GE = 0 since iteration 1500): per run the median PSNR over 2900, 2925, ..., 2999 against the
+    # same statistic of the six oracle records, within 3 standard errors of the difference (no +-3 dB
+    # band); the final forward (what the reference returns) likewise
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stats import delta_with_se
+    its = list(g["oracle_psnr_iters"])
+    o_end = np.median(g["oracle_psnr"][:, [its.index(t) for t in (2900, 2925, 2950, 2975, 2999)]].astype(np.float64), axis=1)
+    d_med, d_fin = delta_with_se(end_med, o_end), delta_with_se(psnrs, p_ref)
+    print("end-of-solve PSNR: hip median(2900..2999) %s oracle %s delta %.3f +- %.3f; final forward delta %.3f +- %.3f"
+          % (np.round(end_med, 2).tolist(), o_end.round(2).tolist(), d_med[0], d_med[1], d_fin[0], d_fin[1]))
+    for delta, se, _ in (d_med, d_fin):
+        assert se <= 1.0 and abs(delta) <= 3.0 * se + 0.05, (delta, se, end_med, o_end, psnrs, p_ref)   # 8 runs, sd ~2 dB
     assert min(psnrs) >= p_in + 1.0, (psnrs, p_in)
 
 

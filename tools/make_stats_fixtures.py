@@ -6,7 +6,8 @@
   c2_oracle_200it_draws.npz        the reference script's own setting (iters = 200, /root/reference/src/test/
                                    test_immoco.py:65-72) at 320x320 / 10 groups: per slice (1, 4, 9) the loss and the
                                    PSNR of EVERY iteration of 8 draws (fp32 summation orders 0, 1, 2, 3, 5, 7, 11, 13 of
-                                   the hash-grid backward), plus a checksum of the input the draws were run on
+                                   the hash-grid backward), plus a checksum of the input the draws were run on; for slice 1
+                                   also 8 draws with summation orders re-drawn before every step (`*_redraw`)
   c2_oracle_slice1_redraw1400.npz  the first 1400 iterations of the 3000-iteration solve of slice 1 with NEW summation
                                    orders drawn before EVERY step (OracleIMMoCo.redraw): 6 draws, loss and PSNR of every
                                    iteration
@@ -30,6 +31,15 @@ for sl in (1, 4, 9):
     out[f"s{sl}_order"] = np.array([int(d["order"]) for d in ds], dtype=np.int32)
     out[f"s{sl}_kspace_abs_sum"] = np.float64(np.abs(ds[0]["kspace"]).astype(np.float64).sum())
     out[f"s{sl}_n_groups"] = np.int32(ds[0]["n_groups"])
+    rs = [np.load(f) for f in sorted(glob.glob(os.path.join(src, f"s{sl}_200rd_*.npz")))]
+    rs = [d for d in rs if int(d["iters_done"]) == 200 and int(d["sched_iters"]) == 200 and int(d["redraw_seed"]) >= 0
+          and np.array_equal(d["kspace"], ds[0]["kspace"])]
+    if rs:   # the same with summation orders re-drawn before every step (OracleIMMoCo.redraw)
+        out[f"s{sl}_loss_redraw"] = np.array([d["loss"] for d in rs], dtype=np.float32)
+        out[f"s{sl}_psnr_redraw"] = np.array([d["psnr_all"] for d in rs], dtype=np.float32)
+        pr = out[f"s{sl}_psnr_redraw"]
+        print(f"slice {sl}: {len(rs)} redraw draws, final PSNR {np.round(pr[:, -1], 2)} mean {pr[:, -1].mean():.3f}; "
+              f"median of last 21: {np.round(np.median(pr[:, 179:], axis=1), 2)} mean {np.median(pr[:, 179:], axis=1).mean():.3f}")
     p = out[f"s{sl}_psnr"]
     print(f"slice {sl}: {len(ds)} draws, final PSNR {np.round(p[:, -1], 2)} mean {p[:, -1].mean():.3f} sd {p[:, -1].std(ddof=1):.3f}; "
           f"median of last 21: {np.round(np.median(p[:, 179:], axis=1), 2)}")
