@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iters", type=int, default=3000, help="Adam iterations per slice (BASELINE: 3000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the informational line in the other arithmetic")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-parts", type=int, default=0, help="transposed-index parts (0 = library default)")
     ap.add_argument("--table-fp16", action="store_true",
@@ -366,6 +367,27 @@ def main():
             "psnr_delta_vs_ref": psnr_delta,
             "roofline": roofline,
         }
+        if world == 1 and args.workload == "c2" and not args.no_alt_precision:
+            # the other arithmetic on the same slices, outside the timed region (3 slices): the line the default is NOT
+            alt16 = not args.mlp_fp16
+            alt_solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16, 0,
+                                    mlp_fp16=alt16)
+            n_alt = min(3, K)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            alt_imgs = [pkg.imcoco_motion_correction(tsl[j]["kspace"], tsl[j]["masks"], iters=args.iters, learning_rate=1e-2,
+                                                     lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts,
+                                                     table_fp16=args.table_fp16, mlp_fp16=alt16)[0] for j in range(n_alt)]
+            torch.cuda.synchronize()
+            dta = time.perf_counter() - ta
+            out["other_precision"] = {
+                "dtype": "f16mlp/f32acc" if alt16 else "f32", "slices": n_alt, "value": round(n_alt / dta, 5), "unit": "slices/s",
+                "ms_per_iteration": round(dta / n_alt / args.iters * 1e3, 4),
+                "psnr_db": [round(crop_psnr(alt_imgs[j].abs().cpu(), tsl[j]["gt"].abs().cpu()), 3) for j in range(n_alt)],
+                "note": "f16mlp: both MLPs with fp16 operands, fp32 accumulation, fp16 activations between the kernels "
+                        "(tiny-cuda-nn's network precision, /root/reference/src/models/immoco.py:11-25,60-65); everything else fp32. "
+                        "Same slices as the timed run, outside the timed region; not the headline (DESIGN.md 2.2, 2.3)"}
+            del alt_solver
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -132,7 +132,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // cfg.mlp_fp16: the encodings (and dL/d enc, scaled by tcnn's loss scale) live as packed halves, one 4-byte word
   // per (point, level), like tiny-cuda-nn's fp16 encoding output / dL/dinput: half the bytes for the two MLP
   // kernels and 4-byte gathers for the encode backward.  (The generic atomic scatter reads fp32: fp32 buffers then.)
-  const bool act16 = s->cfg.mlp_fp16 && !s->cfg.atomic_scatter;
+  static const bool act16_env = [] { const char* e = getenv("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
+  const bool act16 = s->cfg.mlp_fp16 && !s->cfg.atomic_scatter && act16_env;
   const int64_t e_ps = act16 ? 1 : 2;                  // strides of the level-major encodings, in 4-byte words
   const int64_t e_ls_m = act16 ? NP : 2 * NP, e_ls_i = act16 ? P : 2 * P;
 
@@ -533,7 +534,8 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   // in one launch, each into its own partial gradient table (summed by Adam), further ones in following launches
   // (with cfg.mlp_fp16 dL/denc is stored as packed halves: half the bytes per point, half the parts - at 320x320x10
   // 2 parts instead of 4: encode backward 0.386 -> 0.374 ms, motion Adam 0.069 -> 0.054 ms, iteration 1.042 -> 1.020)
-  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W, cfg->mlp_fp16 && !cfg->atomic_scatter ? 4 : 8);
+  const bool act16_on = [] { const char* e = getenv("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
+  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W, cfg->mlp_fp16 && !cfg->atomic_scatter && act16_on ? 4 : 8);
   s->mot_parts = cfg->atomic_scatter ? 1 : (cfg->grad_parts > 0 ? cfg->grad_parts : auto_parts);
   s->mot_tables = std::min(s->mot_parts, 8);
   s->mot_gstride = (s->n_params_mot + 3) / 4 * 4;
