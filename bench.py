@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--grad-parts", type=int, default=0, help="transposed-index parts (0 = library default)")
     ap.add_argument("--table-fp16", action="store_true",
                     help="fp16 hash-grid features (BASELINE config 5 precision); default fp32 like config 2")
-    ap.add_argument("--precision", choices=["f32", "f16mlp"], default=DEFAULT_PRECISION,
+    ap.add_argument("--precision", choices=["f32", "f16mlp", "bf16x2"], default=DEFAULT_PRECISION,
                     help="f32: exact fp32 everywhere; f16mlp: both MLPs with fp16 operands / fp32 accumulation and fp16 "
                          "activations between the kernels (tiny-cuda-nn's network precision; tables, Adam, warp, FFT and "
                          "losses stay fp32)")
@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="slices in flight side by side (c3; 1 is fastest)")
     ap.add_argument("--pair", action="store_true", help="c3: two slices per graph, gathers serialised (batch_pair)")
     args = ap.parse_args()
-    args.mlp_fp16 = bool(args.mlp_fp16 or args.precision == "f16mlp")
+    args.mlp_fp16 = 2 if args.precision == "bf16x2" else int(bool(args.mlp_fp16 or args.precision == "f16mlp"))
     global H, W, N_MOVEMENTS
     if args.workload == "c5":
         H = W = 640
@@ -354,8 +354,9 @@ def main():
             "value": round(value, 5), "unit": "slices/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {(False, False): "f32", (True, False): "f32+f16tab", (False, True): "f16mlp/f32acc",
-                      (True, True): "f16mlp+f16tab/f32acc"}[(bool(args.table_fp16), bool(args.mlp_fp16))],
+            "dtype": {(False, 0): "f32", (True, 0): "f32+f16tab", (False, 1): "f16mlp/f32acc", (True, 1): "f16mlp+f16tab/f32acc",
+                      (False, 2): "f32 (MLP products: bf16x2 split, f32 accumulate)",
+                      (True, 2): "f32+f16tab (MLP products: bf16x2 split)"}[(bool(args.table_fp16), int(args.mlp_fp16))],
             "data": "synthetic",
             "config": {"workload": {"c2": "C2: single 320x320 slice, 10 motion groups, 3000 Adam iters, hash-grid INRs",
                                     "c3": f"C3: batch of {B} independent 320x320 slices on one GPU, {args.lanes} in flight",
@@ -369,7 +370,7 @@ def main():
         }
         if world == 1 and args.workload == "c2" and not args.no_alt_precision:
             # the other arithmetic on the same slices, outside the timed region (3 slices): the line the default is NOT
-            alt16 = not args.mlp_fp16
+            alt16 = 0 if args.mlp_fp16 == 1 else 1
             alt_solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16, 0,
                                     mlp_fp16=alt16)
             n_alt = min(3, K)

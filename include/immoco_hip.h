@@ -136,6 +136,18 @@ int immoco_mlp_bwd_half(const immoco_mlp_cfg* cfg, const float* in, int64_t in_p
                         const float* dout /*[n][n_out]*/, float loss_scale, float* din, float* dw1,
                         float* dw2, void* stream);
 
+/* The same MLP at (nearly) fp32 accuracy on the 16-bit matrix cores: every operand of a matrix product is split into
+ * two bf16 terms (16 significant bits, fp32's exponent range: nothing is scaled), a product is three
+ * v_mfma_f32_32x32x16_bf16 accumulated in fp32; activations, their derivatives and all sums are fp32.  Relative error
+ * of a product <= 2^-16.5 (fp16 operands: 2^-11; the reference's tiny-cuda-nn networks run in fp16,
+ * /root/reference/src/models/immoco.py:11-25,60-65).  Same layouts and accumulate semantics as immoco_mlp_fwd / _bwd. */
+int immoco_mlp_fwd_bf16x2(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                          int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                          float* out, void* stream);
+int immoco_mlp_bwd_bf16x2(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                          int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                          const float* dout /*[n][n_out]*/, float* din, float* dw1, float* dw2, void* stream);
+
 /* ---- parameter init (tcnn: encoding U(-1e-4,1e-4), MLP Xavier-uniform on the
  *      padded shapes; counter-based generator shared bit-exactly with the oracle) */
 int immoco_init_params(const immoco_grid_cfg* grid, const immoco_mlp_cfg* mlp, uint32_t seed,
@@ -241,7 +253,9 @@ typedef struct immoco_solver_cfg {
                              with the streams on separate hardware queues (GPU_MAX_HW_QUEUES=12): 2 lanes 1.55,
                              3 lanes 1.65 ms per slice-iteration against 1.36 serial - two slices' hash-grid
                              gathers evict each other's 4 MB level slices from the XCD L2s */
-  int32_t mlp_fp16;       /* 1: both MLPs in tiny-cuda-nn's network precision (immoco_mlp_fwd_half / _bwd_half: fp16
+  int32_t mlp_fp16;       /* MLP arithmetic.  0: exact fp32 on the f32 MFMA.  2: two-term bf16 split of every matrix operand,
+                             fp32 accumulation (immoco_mlp_fwd_bf16x2 / _bwd_bf16x2; product error <= 2^-16.5).
+                             1: both MLPs in tiny-cuda-nn's network precision (immoco_mlp_fwd_half / _bwd_half: fp16
                              operands, fp32 accumulation, loss scale 128); with table_fp16 this is "tcnn's own
                              arithmetic" (immoco.py:11-25,60-65).  default 0: exact fp32 on the f32 MFMA */
   int32_t batch_pair;     /* immoco_solver_solve_batch: 1 = slices are solved two at a time inside ONE captured graph whose

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "immoco_mlp_bwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "immoco_mlp_fwd_half": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "immoco_mlp_bwd_half": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "immoco_mlp_fwd_bf16x2": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "immoco_mlp_bwd_bf16x2": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "immoco_init_params": (C.c_int, [_GP, _MP, _U32, _P, _P]),
     "immoco_warp_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "immoco_warp_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),

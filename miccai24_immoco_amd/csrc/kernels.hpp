@@ -49,6 +49,14 @@ int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, i
                        const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                        hipStream_t st, int64_t dout_plane, float scale, bool enc_half = false);
 
+// mlp_bf16x2.hip - (nearly) fp32 accuracy on the 16-bit matrix cores: every operand split into two bf16 terms, three
+// MFMAs per product, fp32 everywhere else (relative product error <= 2^-16.5)
+int launch_mlp_fwd_bf16x2(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                          const float* w1, const float* w2, float* out, hipStream_t st);
+int launch_mlp_bwd_bf16x2(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
+                          const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
+                          hipStream_t st, int64_t dout_plane);
+
 // warp.hip
 int launch_warp_fwd(const float* image, const float* grids, int nM, int H, int W, float* out, hipStream_t st);
 int launch_warp_bwd(const float* image, const float* grids, const float* dout, int nM, int H, int W,

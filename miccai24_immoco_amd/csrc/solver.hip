@@ -133,7 +133,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // per (point, level), like tiny-cuda-nn's fp16 encoding output / dL/dinput: half the bytes for the two MLP
   // kernels and 4-byte gathers for the encode backward.  (The generic atomic scatter reads fp32: fp32 buffers then.)
   static const bool act16_env = [] { const char* e = getenv("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
-  const bool act16 = s->cfg.mlp_fp16 && !s->cfg.atomic_scatter && act16_env;
+  const bool act16 = s->cfg.mlp_fp16 == 1 && !s->cfg.atomic_scatter && act16_env;
   const int64_t e_ps = act16 ? 1 : 2;                  // strides of the level-major encodings, in 4-byte words
   const int64_t e_ls_m = act16 ? NP : 2 * NP, e_ls_i = act16 ? P : 2 * P;
 
@@ -150,6 +150,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     return launch_hashgrid_fwd(s->lv_mot, nullptr, &lm, NP, tabm, s->enc_mot, e_ps, e_ls_m, q, act16);
                   }, 1});
     st.push_back({"motion_mlp_fwd", [=](hipStream_t q) {
+                    if (s->cfg.mlp_fp16 == 2)
+                      return launch_mlp_fwd_bf16x2(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
                     if (s->cfg.mlp_fp16)
                       return launch_mlp_fwd_f16(s->cfg.motion_mlp, s->enc_mot, e_ps, e_ls_m, NP, w1m, w2m, s->o_mot, q, act16);
                     return launch_mlp_fwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot, q);
@@ -163,6 +165,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   return launch_hashgrid_fwd(s->lv_img, nullptr, &li, P, tabi, s->enc_img, e_ps, e_ls_i, q, act16);
                 }, 2});
   st.push_back({"image_mlp_fwd", [=](hipStream_t q) {
+                  if (s->cfg.mlp_fp16 == 2)
+                    return launch_mlp_fwd_bf16x2(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
                   if (s->cfg.mlp_fp16)
                     return launch_mlp_fwd_f16(s->cfg.image_mlp, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->image, q, act16);
                   return launch_mlp_fwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
@@ -204,13 +208,16 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     const char* e = getenv("IMMOCO_FORK");
     return !e ? -1 : (strcmp(e, "early") == 0 ? 1 : 0);
   }();
-  const bool fork_early = fork_env >= 0 ? fork_env == 1 : s->cfg.mlp_fp16 != 0;
+  const bool fork_early = fork_env >= 0 ? fork_env == 1 : false;   // measured slower in every mode
   if (nM > 0) {
     st.push_back({"motion_warp_bwd", [=](hipStream_t q) {
                     return launch_motion_warp_bwd(s->image, s->t_mot, s->xs, s->ys, slot1, nM, H, W, s->dimage,
                                                   s->o_mot, q);
                   }});
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
+                    if (s->cfg.mlp_fp16 == 2)
+                      return launch_mlp_bwd_bf16x2(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
+                                                   s->enc_mot, g_w1m, g_w2m, q, 0);
                     if (s->cfg.mlp_fp16)
                       return launch_mlp_bwd_f16(s->cfg.motion_mlp, s->enc_mot, e_ps, e_ls_m, NP, w1m, w2m, s->o_mot,
                                                 s->enc_mot, g_w1m, g_w2m, q, 0, TCNN_LOSS_SCALE, act16);
@@ -245,6 +252,9 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // the rocprofv3 stats - and slows that gather from 0.45 to 0.58 ms; run BEFORE the fork instead, alone, the
   // iteration takes 1.435 ms instead of 1.351: the overlap is still worth more than it costs.)
   st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
+                  if (s->cfg.mlp_fp16 == 2)
+                    return launch_mlp_bwd_bf16x2(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
+                                                 g_w1i, g_w2i, q, /*planar dimage*/ P);
                   if (s->cfg.mlp_fp16)
                     return launch_mlp_bwd_f16(s->cfg.image_mlp, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->dimage,
                                               s->enc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16);
@@ -535,7 +545,7 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   // (with cfg.mlp_fp16 dL/denc is stored as packed halves: half the bytes per point, half the parts - at 320x320x10
   // 2 parts instead of 4: encode backward 0.386 -> 0.374 ms, motion Adam 0.069 -> 0.054 ms, iteration 1.042 -> 1.020)
   const bool act16_on = [] { const char* e = getenv("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
-  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W, cfg->mlp_fp16 && !cfg->atomic_scatter && act16_on ? 4 : 8);
+  const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W, cfg->mlp_fp16 == 1 && !cfg->atomic_scatter && act16_on ? 4 : 8);
   s->mot_parts = cfg->atomic_scatter ? 1 : (cfg->grad_parts > 0 ? cfg->grad_parts : auto_parts);
   s->mot_tables = std::min(s->mot_parts, 8);
   s->mot_gstride = (s->n_params_mot + 3) / 4 * 4;

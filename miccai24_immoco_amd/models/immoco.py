@@ -143,6 +143,21 @@ class IMMoCo(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # fused solver
 # ----------------------------------------------------------------------------------------------
+def mlp_mode(mlp_fp16) -> int:
+    """immoco_solver_cfg.mlp_fp16 from the Python keyword: False / 0 -> exact fp32; True / 1 / "f16" -> tiny-cuda-nn's
+    network precision (fp16 operands, fp32 accumulation, loss scale 128, fp16 activations between the kernels);
+    "bf16x2" / 2 -> every matrix operand split into two bf16 terms (product error <= 2^-16.5), fp32 otherwise."""
+    if isinstance(mlp_fp16, str):
+        try:
+            return {"f32": 0, "fp32": 0, "f16": 1, "fp16": 1, "f16mlp": 1, "bf16x2": 2}[mlp_fp16.lower()]
+        except KeyError:
+            raise L.ImmocoError(f"unknown MLP precision {mlp_fp16!r}") from None
+    m = int(mlp_fp16)
+    if m not in (0, 1, 2):
+        raise L.ImmocoError(f"unknown MLP precision {mlp_fp16!r}")
+    return m
+
+
 class _SolverHandle:
     """RAII wrapper of immoco_solver_t; cached per (device, H, W, nM)."""
 
@@ -155,7 +170,7 @@ class _SolverHandle:
         self.motion_mlp = L.mlp_cfg(32, 2, mot_network_config)
         cfg = L.SolverCfg(H, W, nM, self.image_grid, self.motion_grid, self.image_mlp, self.motion_mlp,
                           1 if use_graph else 0, 1 if atomic_scatter else 0, int(grad_parts),
-                          2 if serial_chains is None else (1 if serial_chains else 0), 1 if table_fp16 else 0, int(batch_lanes), 1 if mlp_fp16 else 0,
+                          2 if serial_chains is None else (1 if serial_chains else 0), 1 if table_fp16 else 0, int(batch_lanes), mlp_mode(mlp_fp16),
                           1 if batch_pair else 0)
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
@@ -267,7 +282,7 @@ def get_solver(device, H, W, nM, use_graph=True, atomic_scatter=False, grad_part
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     key = (device.index, H, W, nM, bool(use_graph), bool(atomic_scatter), int(grad_parts), int(instance),
-           bool(table_fp16), int(batch_lanes), bool(mlp_fp16), serial_chains, bool(batch_pair))
+           bool(table_fp16), int(batch_lanes), mlp_mode(mlp_fp16), serial_chains, bool(batch_pair))
     s = _SOLVERS.get(key)
     if s is None:
         s = _SOLVERS[key] = _SolverHandle(device, H, W, nM, use_graph, atomic_scatter, grad_parts, table_fp16,

@@ -1,0 +1,27 @@
+"""Median-of-last-21 PSNR of N HIP solves of the 200-iteration schedule on one C2 slice (GPU box).
+    python tools/diag_200.py <slice> [N=64] [--mlp-fp16 | --bf16x2]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import miccai24_immoco_amd as pkg
+from miccai24_immoco_amd import synth
+from miccai24_immoco_amd.models.immoco import get_solver
+from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+from oracle import synth_cpu
+from _stats import hip_psnr_samples, summarize
+a = [x for x in sys.argv[1:] if not x.startswith("--")]
+sl, N = int(a[0]), (int(a[1]) if len(a) > 1 else 64)
+s_ = synth_cpu.make_slice(320, 320, 10, sl)
+k, lines = s_["kspace"].cuda(), s_["lines"].cuda()
+masks = pkg.extract_movement_groups(lines, make_list=True)
+gt = synth.phantom(320, 320, 1000 + sl).abs()
+sol = get_solver(torch.device("cuda", 0), 320, 320, int(masks.shape[0]),
+                 mlp_fp16=("bf16x2" if "--bf16x2" in sys.argv else "--mlp-fp16" in sys.argv))
+kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
+h = []
+for r in range(N):
+    ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, list(range(179, 200)))
+    h.append(float(np.median(list(ps.values()))))
+print("slice", sl, [x for x in sys.argv if x.startswith("--")], N, "runs: median-of-last-21 PSNR mean %.3f sd %.3f se %.3f" % summarize(h),
+      "median %.2f" % np.median(h))

@@ -16,7 +16,7 @@ s_ = synth_cpu.make_slice(320, 320, 10, 1)
 k, lines = s_["kspace"].cuda(), s_["lines"].cuda()
 masks = pkg.extract_movement_groups(lines, make_list=True)
 gt = synth.phantom(320, 320, 1001).abs()
-sol = get_solver(torch.device("cuda", 0), 320, 320, 10, mlp_fp16="--mlp-fp16" in sys.argv)
+sol = get_solver(torch.device("cuda", 0), 320, 320, 10, mlp_fp16=("bf16x2" if "--bf16x2" in sys.argv else "--mlp-fp16" in sys.argv))
 kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
 grid = list(range(600, 1400, 25))
 h = []

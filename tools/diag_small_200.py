@@ -1,5 +1,5 @@
 """HIP side of the small-scale 200-iteration experiment (96x96, 3 groups, slice 11): N runs, median PSNR / loss of the
-last 21 iterations (GPU box).     python tools/diag_small_200.py [N=32] [--mlp-fp16]"""
+last 21 iterations (GPU box).     python tools/diag_small_200.py [N=32] [--mlp-fp16 | --bf16x2]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,7 @@ s_ = synth_cpu.make_slice(96, 96, 3, 11)
 k, lines = s_["kspace"].cuda(), s_["lines"].cuda()
 masks = pkg.extract_movement_groups(lines, make_list=True)
 gt = s_["gt"].abs()
-sol = get_solver(torch.device("cuda", 0), 96, 96, int(masks.shape[0]), mlp_fp16="--mlp-fp16" in sys.argv)
+sol = get_solver(torch.device("cuda", 0), 96, 96, int(masks.shape[0]), mlp_fp16=("bf16x2" if "--bf16x2" in sys.argv else "--mlp-fp16" in sys.argv))
 kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
 ps_, ls_ = [], []
 for r in range(N):
