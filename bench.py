@@ -34,10 +34,12 @@ sys.path.insert(0, ROOT)
 H = W = 320
 N_MOVEMENTS = 10
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Arithmetic of the default line.  The reference's INRs run in fp16 (tiny-cuda-nn `__half` networks, loss scale 128:
-# /root/reference/src/models/immoco.py:11-25,60-65).  "f16mlp" rounds exactly what tcnn's network rounds and nothing
-# else (fp32 accumulation, fp32 tables / Adam / warp / FFT / losses): never narrower than the reference, and
-# statistically indistinguishable from the fp32 oracle on the suite's distribution tests.
+# Arithmetic of the default line: exact fp32.  The reference's INRs run in fp16 (tiny-cuda-nn `__half` networks, loss
+# scale 128: /root/reference/src/models/immoco.py:11-25,60-65), so the two faster MLP arithmetics of this build -
+# "f16mlp" (fp16 operands, fp32 accumulation: 1.02 ms per iteration) and "bf16x2" (two-term bf16 split: 1.15 ms) - are
+# never narrower than the reference; but against the fp32 oracle their PSNR statistics are distinguishable (f16mlp: up
+# to -1.4 dB at 200 iterations; bf16x2: more low-plateau runs, 3 s.e. at 80 runs), so they are reported as
+# `other_precision` lines of the same run and the headline stays fp32.
 DEFAULT_PRECISION = "f32"
 
 
@@ -306,7 +308,9 @@ def main():
         b_iter = (30 if args.table_fp16 else 28) * (solver.n_params_image + solver.n_params_motion) + 8 * H * W
         iter_ms_graph = ms_per_step / args.iters / B
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if args.workload != "c5" else "r02_traffic_c5.json")
+        tname = "r03_traffic" + ("_c5" if args.workload == "c5" else "") + \
+            ({0: "", 1: "_f16mlp", 2: "_bf16x2"}[int(args.mlp_fp16)]) + ".json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -369,26 +373,32 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and args.workload == "c2" and not args.no_alt_precision:
-            # the other arithmetic on the same slices, outside the timed region (3 slices): the line the default is NOT
-            alt16 = 0 if args.mlp_fp16 == 1 else 1
-            alt_solver = get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16, 0,
-                                    mlp_fp16=alt16)
-            n_alt = min(3, K)
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            alt_imgs = [pkg.imcoco_motion_correction(tsl[j]["kspace"], tsl[j]["masks"], iters=args.iters, learning_rate=1e-2,
-                                                     lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts,
-                                                     table_fp16=args.table_fp16, mlp_fp16=alt16)[0] for j in range(n_alt)]
-            torch.cuda.synchronize()
-            dta = time.perf_counter() - ta
-            out["other_precision"] = {
-                "dtype": "f16mlp/f32acc" if alt16 else "f32", "slices": n_alt, "value": round(n_alt / dta, 5), "unit": "slices/s",
-                "ms_per_iteration": round(dta / n_alt / args.iters * 1e3, 4),
-                "psnr_db": [round(crop_psnr(alt_imgs[j].abs().cpu(), tsl[j]["gt"].abs().cpu()), 3) for j in range(n_alt)],
-                "note": "f16mlp: both MLPs with fp16 operands, fp32 accumulation, fp16 activations between the kernels "
-                        "(tiny-cuda-nn's network precision, /root/reference/src/models/immoco.py:11-25,60-65); everything else fp32. "
-                        "Same slices as the timed run, outside the timed region; not the headline (DESIGN.md 2.2, 2.3)"}
-            del alt_solver
+            # the other MLP arithmetics on the same slices, outside the timed region (2 slices each): informational lines
+            labels = {0: "f32", 1: "f16mlp/f32acc", 2: "f32 (MLP products: bf16x2 split, f32 accumulate)"}
+            notes = {0: "exact fp32 everywhere",
+                     1: "both MLPs with fp16 operands, fp32 accumulation, fp16 activations between the kernels: tiny-cuda-nn's "
+                        "network precision (/root/reference/src/models/immoco.py:11-25,60-65); measurably below fp32 in PSNR at 200 "
+                        "iterations (up to -1.4 dB), not resolvable at 3000 (DESIGN.md 2.2, 2.3)",
+                     2: "every MLP matrix operand split into two bf16 terms (product error <= 2^-16.5), everything else fp32 "
+                        "(DESIGN.md 4.3)"}
+            out["other_precision"] = []
+            n_alt = min(2, K)
+            for mode in (0, 1, 2):
+                if mode == int(args.mlp_fp16):
+                    continue
+                get_solver(dev, H, W, nM, not args.no_graph, False, args.grad_parts, 0, args.table_fp16, 0, mlp_fp16=mode)
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                alt_imgs = [pkg.imcoco_motion_correction(tsl[j]["kspace"], tsl[j]["masks"], iters=args.iters, learning_rate=1e-2,
+                                                         lambda_ge=1e-2, use_graph=not args.no_graph, grad_parts=args.grad_parts,
+                                                         table_fp16=args.table_fp16, mlp_fp16=mode)[0] for j in range(n_alt)]
+                torch.cuda.synchronize()
+                dta = time.perf_counter() - ta
+                out["other_precision"].append({
+                    "dtype": labels[mode], "slices": n_alt, "value": round(n_alt / dta, 5), "unit": "slices/s",
+                    "ms_per_iteration": round(dta / n_alt / args.iters * 1e3, 4),
+                    "psnr_db": [round(crop_psnr(alt_imgs[j].abs().cpu(), tsl[j]["gt"].abs().cpu()), 3) for j in range(n_alt)],
+                    "note": notes[mode] + "; same slices as the timed run, outside the timed region"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1,14 +1,24 @@
-# round-end evidence: the default bench command, its rocprofv3 kernel stats, and the PMC traffic passes
-# (separate --pmc runs, kernel trace only).  Every step must succeed before the next GPU step starts.
+# round-end evidence (round 3): the default bench command, its rocprofv3 kernel stats, the PMC traffic passes (separate
+# --pmc runs, kernel trace only), the informational lines and the iteration timelines.  Every GPU step must succeed
+# before the next one starts.
 set -e -o pipefail
 mkdir -p gpurun_out/final
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python3 bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
-tail -1 gpurun_out/final/bench_default.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt_default -- python3 bench.py --no-cpu-baseline > gpurun_out/final/kt_default.log 2>&1
+timeout -k 10 900 python3 bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+tail -n 1 gpurun_out/final/bench_default.json | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt_default -- python3 bench.py --no-cpu-baseline --no-alt-precision > gpurun_out/final/kt_default.log 2>&1
 rm -f gpurun_out/final/kt_default/*/*_kernel_trace.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final/fetch -- python3 bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final/write -- python3 bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/write.log 2>&1
-rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/final/l2req -- python3 bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/l2req.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final/fetch -- python3 bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline --no-alt-precision > gpurun_out/final/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final/write -- python3 bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline --no-alt-precision > gpurun_out/final/write.log 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/final/l2req -- python3 bench.py --iters 20 --steps 1 --warmup 0 --no-cpu-baseline --no-alt-precision > gpurun_out/final/l2req.log 2>&1
 rm -f gpurun_out/final/fetch/*/*_kernel_trace.csv gpurun_out/final/write/*/*_kernel_trace.csv gpurun_out/final/l2req/*/*_kernel_trace.csv
+for prec in f16mlp bf16x2; do
+  python3 bench.py --precision $prec --no-cpu-baseline --no-alt-precision > gpurun_out/final/bench_$prec.json 2> gpurun_out/final/bench_$prec.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt_$prec -- python3 bench.py --precision $prec --steps 1 --warmup 1 --no-cpu-baseline --no-alt-precision > gpurun_out/final/kt_$prec.log 2>&1
+  rm -f gpurun_out/final/kt_$prec/*/*_kernel_trace.csv
+done
+python3 bench.py --workload c3 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_c3_serial.json 2> gpurun_out/final/bench_c3_serial.err
+python3 bench.py --workload c3 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --pair > gpurun_out/final/bench_c3_pair.json 2> gpurun_out/final/bench_c3_pair.err
+python3 bench.py --workload c3 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --pair --precision f16mlp > gpurun_out/final/bench_c3_pair_f16mlp.json 2> gpurun_out/final/bench_c3_pair_f16mlp.err
+python3 bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_c5.json 2> gpurun_out/final/bench_c5.err
 ls gpurun_out/final/kt_default/*/

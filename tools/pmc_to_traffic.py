@@ -15,6 +15,10 @@ src, tag = sys.argv[1], sys.argv[2]
 traffic_name = tag.split("_")[0] + "_traffic.json"      # r02_final -> profiles/r02_traffic.json (read by bench.py)
 PHASE = [("hashgrid_fwd_kernel<2", "image_encode_fwd"), ("hashgrid_fwd_kernel<3", "motion_encode_fwd"),
          ("mlp_fwd_mfma_kernel<256", "image_mlp_fwd"), ("mlp_fwd_mfma_kernel<64", "motion_mlp_fwd"),
+         ("mlp_fwd_f16_kernel<256", "image_mlp_fwd"), ("mlp_fwd_f16_kernel<64", "motion_mlp_fwd"),
+         ("mlp_bwd_f16_kernel<256", "image_mlp_bwd"), ("mlp_bwd_f16_kernel<64", "motion_mlp_bwd"),
+         ("mlp_fwd_bf16x2_kernel<256", "image_mlp_fwd"), ("mlp_fwd_bf16x2_kernel<64", "motion_mlp_fwd"),
+         ("mlp_bwd_bf16x2_kernel<256", "image_mlp_bwd"), ("mlp_bwd_bf16x2_kernel<64", "motion_mlp_bwd"),
          ("motion_warp_fwd_kernel", "motion_warp_fwd"), ("motion_warp_bwd", "motion_warp_bwd"),
          ("mlp_bwd_mfma_kernel<256", "image_mlp_bwd"), ("mlp_bwd_mfma_kernel<64", "motion_mlp_bwd"),
          ("csr_bwd_kernel<3", "motion_encode_bwd"), ("csr_bwd_kernel<2", "image_encode_bwd"),
