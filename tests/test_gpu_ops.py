@@ -302,6 +302,47 @@ def test_inr_module_vs_oracle(env, which):
         assert (a - b).abs().max() <= 2e-4 * a.abs().max(), ((a - b).abs().max(), a.abs().max())
 
 
+def test_inr_module_plan_cache_follows_the_input(env):
+    """the lattice plan of the tcnn-compatible module is cached per input tensor.  The key
+    (address, shape, strides, dtype, version) only identifies a tensor while its memory lives, so the module keeps the
+    keyed tensor alive; a freed lattice whose block the caching allocator hands to a NON-lattice tensor of the same
+    shape must not be served the old plan: the sequence lattice -> (free) -> random points of the same shape ->
+    in-place modified lattice gives the results of a module without plans each time, and modes / precisions of the
+    module (`mlp_fp16`) do not share state."""
+    pkg, L, orc = env
+    mod = pkg.NetworkWithInputEncoding(3, 2, pkg.encoding_config, pkg.mot_network_config, seed=5)
+    ref = pkg.NetworkWithInputEncoding(3, 2, pkg.encoding_config, pkg.mot_network_config, seed=5, lattice_plans=False)
+    with torch.no_grad():
+        mod.params[3072:] *= 1000
+        ref.params.copy_(mod.params)
+
+    def both(x):
+        outs = []
+        for m in (mod, ref):
+            m.zero_grad()
+            o = m(x)
+            (o * o).sum().backward()
+            outs.append((o.detach().clone(), m.params.grad.clone()))
+        np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        a, b = outs[0][1], outs[1][1]
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+        return mod._plan is not None
+
+    x1 = orc.make_grids((3, 16, 20)).cuda()
+    assert both(x1) is True                                   # a lattice: planned backward
+    shape, ptr = tuple(x1.shape), x1.data_ptr()
+    del x1
+    torch.cuda.synchronize()
+    x2 = (torch.rand(shape, device="cuda") * 2 - 1)           # may or may not land on the freed block
+    assert mod._plan_owner is not None and mod._plan_owner.data_ptr() == ptr      # ... it cannot: the module holds it
+    assert x2.data_ptr() != ptr
+    assert both(x2) is False                                  # not a lattice: generic scatter, no stale plan
+    x3 = orc.make_grids((3, 16, 20)).cuda()
+    assert both(x3) is True
+    x3[5, 2] += 0.25                                          # in-place change: version bump, no longer a lattice
+    assert both(x3) is False
+
+
 @pytest.mark.parametrize("dims", [2, 3])
 def test_inr_module_other_grid_config_vs_oracle(env, dims):
     """The tcnn-compatible module is not tied to the reference's grid numbers: a smaller hash map, another
