@@ -1490,7 +1490,7 @@ def test_config2_lambda_positive_regime_vs_oracle_draws(env, golden, mlp):
     k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
     sol = get_solver(torch.device("cuda", 0), 320, 320, 10, mlp_fp16=mlp)
     h, ev_h = [], []
-    for _ in range(24):
+    for _ in range(24 if not mlp else 14):
         ps, loss = hip_psnr_samples(sol, kin, cg, gt, 3000, grid + [1399])
         h.append(float(np.median([ps[t] for t in grid])))
         ev_h.append(_blowups(loss.astype(np.float64), 300, 1400))
@@ -1569,7 +1569,7 @@ def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, gold
     kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
     samples = list(range(179, 200))
     h_med, h_fin, h_loss = [], [], []
-    for _ in range(32):
+    for _ in range(32 if mode == "f32" else 24):
         ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, samples)
         h_med.append(float(np.median([ps[t] for t in samples])))
         h_fin.append(ps[199])
