@@ -24,4 +24,4 @@ for r in range(N):
     ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, list(range(179, 200)))
     h.append(float(np.median(list(ps.values()))))
 print("slice", sl, [x for x in sys.argv if x.startswith("--")], N, "runs: median-of-last-21 PSNR mean %.3f sd %.3f se %.3f" % summarize(h),
-      "median %.2f" % np.median(h))
+      "median %.2f" % np.median(h), "deciles", np.round(np.quantile(h, np.linspace(0.1, 0.9, 9)), 2).tolist())
