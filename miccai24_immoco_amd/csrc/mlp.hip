@@ -181,19 +181,26 @@ __global__ __launch_bounds__(BWD_THREADS) void mlp_bwd_kernel(
 }
 
 // IMMOCO_MLP_IMPL=valu selects the fp32 VALU kernels of this file (kept for A/B measurements);
-// the default is the matrix-core implementation in mlp_mfma.hip.
-static bool use_valu_impl() {
-  static const bool v = [] {
+// the default is the matrix-core implementation in mlp_mfma.hip.  valu-fwd / valu-bwd / valu-image /
+// valu-motion restrict the switch to one direction or one network (hidden width 256 / 64).
+static bool use_valu_impl(bool bwd, int n_hidden) {
+  static const unsigned v = [] {
     const char* e = getenv("IMMOCO_MLP_IMPL");
-    return e && strcmp(e, "valu") == 0;
-  }();
-  return v;
+    if (!e) return 0u;
+    if (strcmp(e, "valu") == 0) return 15u;
+    if (strcmp(e, "valu-fwd") == 0) return 5u;
+    if (strcmp(e, "valu-bwd") == 0) return 10u;
+    if (strcmp(e, "valu-image") == 0) return 3u;
+    if (strcmp(e, "valu-motion") == 0) return 12u;
+    return 0u;
+  }();   // bit 0 image forward, 1 image backward, 2 motion forward, 3 motion backward
+  return (v >> ((n_hidden == 64 ? 2 : 0) + (bwd ? 1 : 0))) & 1u;
 }
 
 int launch_mlp_fwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                    const float* w1, const float* w2, float* out, hipStream_t st) {
   if (n == 0) return IMMOCO_OK;
-  if (!use_valu_impl()) return launch_mlp_fwd_mfma(cfg, in, ps, ls, n, w1, w2, out, st);
+  if (!use_valu_impl(false, cfg.n_hidden)) return launch_mlp_fwd_mfma(cfg, in, ps, ls, n, w1, w2, out, st);
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   const unsigned grid = (unsigned)cdiv(n, 256);
 #define IMMOCO_FWD(H, A) mlp_fwd_kernel<H, A><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, out)
@@ -210,7 +217,7 @@ int launch_mlp_bwd(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64
                    const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                    hipStream_t st, int64_t dout_plane) {
   if (n == 0) return IMMOCO_OK;
-  if (!use_valu_impl()) return launch_mlp_bwd_mfma(cfg, in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
+  if (!use_valu_impl(true, cfg.n_hidden)) return launch_mlp_bwd_mfma(cfg, in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
   const int64_t n_batches = cdiv(n, 64);
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_batches, 2), 4096);

@@ -53,7 +53,11 @@ __device__ __forceinline__ float tanh_fast(float x) {
 
 template <int ACT>
 __device__ __forceinline__ float act_f(float pre) {
+#ifdef IMMOCO_DIAG_LIBM_TANH   // diagnostics build only (tools/README.md): libm tanhf instead of tanh_fast
+  return ACT == IMMOCO_ACT_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
+#else
   return ACT == IMMOCO_ACT_RELU ? fmaxf(pre, 0.f) : tanh_fast(pre);
+#endif
 }
 // derivative from the activation VALUE (relu: h > 0 <=> pre > 0; tanh: 1 - h^2)
 template <int ACT>

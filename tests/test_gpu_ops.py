@@ -1465,14 +1465,14 @@ def _blowups(loss, a, b, thr=1.5):
 @pytest.mark.parametrize("mlp", [False, "bf16x2"])
 def test_config2_lambda_positive_regime_vs_oracle_draws(env, golden, mlp):
     """VERDICT r2 item 1a - statistical parity where lambda_GE > 0 (iterations 600 ... 1400 of the metric's
-    3000-iteration solve, slice 1), against TWELVE oracle draws: the six fixed-order records
-    (c2_oracle_slice1_3000it.npz) and six draws whose fp32 summation orders are re-drawn before EVERY step
+    3000-iteration solve, slice 1), against NINETEEN oracle draws: the six fixed-order records
+    (c2_oracle_slice1_3000it.npz) and thirteen draws whose fp32 summation orders are re-drawn before EVERY step
     (c2_oracle_slice1_redraw1400.npz, OracleIMMoCo.redraw - what nondeterministic atomics do, in tiny-cuda-nn and here).
     What the records show: every trajectory - oracle and HIP - oscillates with period 2 and goes through
     about one loss blow-up between iterations 1050 and 1460, after which PSNR dips (and sometimes spikes to 44-46 dB)
     for 50-150 iterations.  PSNR at ONE iteration (round 2 compared iteration 1400) therefore measures when the
-    blow-up happened; with re-drawn orders the oracle's own spread at 1375 is 2.5 dB (fixed order: 0.7) and its
-    blow-ups are as large as HIP's (median ratio 7 vs 3 with a fixed order).  Robust statistics instead:
+    blow-up happened; with re-drawn orders the oracle's own spread at 1375 is 2.1 dB (fixed order: 0.7) and its
+    blow-ups are as large as HIP's (median ratio 6.3 vs 3 with a fixed order).  Robust statistics instead:
       * per run, the MEDIAN PSNR over the samples at 600, 625, ..., 1375 (the level of the lambda > 0 plateau);
       * blow-up events per run in 300 ... 1400 and their size."""
     pkg, L, orc = env
@@ -1500,14 +1500,16 @@ def test_config2_lambda_positive_regime_vs_oracle_draws(env, golden, mlp):
     ratios_o = [r for e in ev_o[6:] for _, r in e]       # re-drawn orders: the like-for-like noise model
     print("plateau PSNR (median over 600..1375 every 25): hip mean %.3f sd %.3f | oracle fixed %s redraw %s | delta %.3f +- %.3f"
           % (*summarize(h)[:2], o_fixed.round(2).tolist(), o_redraw.round(2).tolist(), delta, se))
-    print("blow-ups per run in 300..1400: hip %.2f oracle (12 draws) %.2f; ratios hip %s redraw oracle %s fixed-order oracle %s"
+    print("blow-ups per run in 300..1400: hip %.2f oracle (19 draws) %.2f; ratios hip %s redraw oracle %s fixed-order oracle %s"
           % (rate_h, rate_o, np.round(sorted(ratios_h), 1).tolist(), np.round(sorted(ratios_o), 1).tolist(),
              np.round(sorted(r for e in ev_o[:6] for _, r in e), 1).tolist()))
     # The plateau statistic is bimodal on BOTH sides: a run sits at 39.3-40.0 dB, or - after an abrupt drop somewhere
     # between iterations 250 and 900, without any loss event - 2-5 dB lower for hundreds of iterations until the next
-    # blow-up puts it back (tools/diag_lowbasin.py).  Low runs: HIP 16 of 80 / 16 of 48 / 7 of 32 (20-33 %), oracle
-    # with re-drawn orders 1-2 of 6, oracle with a fixed order 0-1 of 6; with single fp16 operands 3 of 32, with the
-    # bf16 split ~1 in 3.  So three robust statements instead of one mean:
+    # blow-up puts it back (tools/diag_lowbasin.py).  Low runs: HIP 87 of 352 (20-33 % per batch), oracle 1 of 19
+    # (re-drawn orders 1 of 13, fixed order 0 of 6).  That fraction is a property of THIS initialisation (the
+    # reference's fixed seed 1337) and of 1e-7-level arithmetic detail - the VALU MLP kernels give 12 of 112, the same
+    # matrix-core kernels on one stream 37 of 96, other init seeds 0 of 24 ... 14 of 24 - and is compared seed by seed in
+    # test_config2_plateau_by_initialisation_vs_oracle_draws.  Here, three robust statements:
     #  (1) the level of the plateau where a run IS on it: upper quartile of the per-run medians, HIP vs oracle;
     q_h, q_o = float(np.quantile(h, 0.75)), float(np.quantile(o_all, 0.75))
     print("upper quartile of the per-run plateau PSNR: hip %.2f oracle %.2f; low runs (< 38 dB): hip %d of %d, oracle %d of %d"
@@ -1516,12 +1518,58 @@ def test_config2_lambda_positive_regime_vs_oracle_draws(env, golden, mlp):
     #  (2) the fraction of low runs is bounded (24 runs resolve it to +-0.1; measured 0.2-0.33 in exact fp32);
     assert sum(v < 38 for v in h) <= 0.55 * len(h), h
     #  (3) the difference of the means stays inside 1.5 dB and is reported with its standard error
-    #      (80 runs: -0.87 +- 0.27 against the twelve draws - the low-run fraction again).
+    #      (80 runs: -0.95 +- 0.23 against the nineteen draws - the low-run fraction again).
     assert se <= 0.6 and abs(delta) <= 1.5, (delta, se, h, o_all)
-    # about one event per run on both sides (12 oracle draws: 0.83); 24 runs resolve the rate to +-0.2
+    # about one event per run on both sides (19 oracle draws: 0.74); 24 runs resolve the rate to +-0.2
     assert 0.3 <= rate_h <= 1.5, (rate_h, ev_h)
     if ratios_h and ratios_o:
         assert 0.33 * np.median(ratios_o) <= np.median(ratios_h) <= 3.0 * np.median(ratios_o), (ratios_h, ratios_o)
+
+
+def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
+    """WHICH runs leave the lambda_GE > 0 plateau is decided by the initial parameters, in HIP and in the oracle alike.
+    With the reference's fixed tcnn seed (1337) a fraction of the runs slides 2-5 dB below the 39.6 dB plateau
+    (test above); that fraction is a property of the initialisation and of 1e-7-level arithmetic detail (HIP, 24 runs
+    per init seed: 0 % for seeds 2002 / 2003 / 2006, 46 % and 58 % for 2005 and 2004; for seed 1337: matrix-core MLP
+    kernels 25 %, the VALU kernels 11 %, the same kernels on one stream 38 %, oracle draws 1 of 19), so HIP and the
+    oracle are compared seed by seed: CPU-oracle draws of the first 1001 iterations from init seeds 2001...2008 with
+    summation orders re-drawn every step (tests/golden/c2_oracle_slice1_initseeds.npz, tools/oracle_c2.py) against 6 HIP
+    runs per seed from the SAME initial parameters (immoco_init_params is bit-identical to the oracle's init).  Per run:
+    the median PSNR over iterations 600, 625, ..., 975."""
+    pkg, L, orc = env
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stats import hip_psnr_samples
+    from miccai24_immoco_amd.models.immoco import get_solver
+    g = golden("c2_oracle_slice1_initseeds")
+    grid = list(range(600, 1000, 25))
+    o_seed = g["init_seed"].astype(int)
+    o_plat = np.median(g["psnr"][:, grid].astype(np.float64), axis=1)
+    k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
+    sol = get_solver(torch.device("cuda", 0), 320, 320, 10)
+    seeds = sorted(set(o_seed.tolist()))
+    hip = {}
+    for sd in seeds:
+        hip[sd] = []
+        for _ in range(6):
+            ps, _ = hip_psnr_samples(sol, kin, cg, gt, 3000, grid, seed=sd)
+            hip[sd].append(float(np.median([ps[t] for t in grid])))
+    for sd in seeds:
+        print("init seed %d: hip %s | oracle %s" % (sd, np.round(hip[sd], 2).tolist(), np.round(o_plat[o_seed == sd], 2).tolist()))
+    LOW = 38.0
+    robust = [sd for sd in seeds if min(hip[sd]) >= 39.0]
+    fragile = [sd for sd in seeds if sum(v < LOW for v in hip[sd]) >= 2]
+    print("robust seeds (no HIP run below 39 dB)", robust, "fragile seeds (>= 2 of 6 HIP runs below 38 dB)", fragile)
+    assert len(robust) >= 2 and len(fragile) >= 1, (robust, fragile, hip)
+    # (1) from a robust initialisation both sit ON the plateau, at the same level
+    for sd in robust:
+        o = o_plat[o_seed == sd]
+        assert o.min() >= LOW, (sd, o, hip[sd])
+        assert abs(float(np.median(o)) - float(np.median(hip[sd]))) <= 0.5, (sd, o, hip[sd])
+    # (2) the oracle's low draws come from the initialisations HIP finds fragile
+    o_low = [int(sd) for sd, v in zip(o_seed, o_plat) if v < LOW]
+    h_frac = {sd: sum(v < LOW for v in hip[sd]) / len(hip[sd]) for sd in seeds}
+    print("oracle low draws from seeds", o_low, "| hip low fraction per seed", h_frac)
+    assert all(h_frac[sd] > 0 or sd not in robust for sd in o_low), (o_low, h_frac)
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x2", "f16mlp"])

@@ -1,5 +1,6 @@
 """Median-of-last-21 PSNR of N HIP solves of the 200-iteration schedule on one C2 slice (GPU box).
-    python tools/diag_200.py <slice> [N=64] [--mlp-fp16 | --bf16x2]"""
+    python tools/diag_200.py <slice> [N=64] [--mlp-fp16 | --bf16x2] [--seeds=K]
+--seeds=K: run r starts from init_params seed 2001 + r % K instead of the reference's fixed 1337 (per-seed means printed)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,9 +20,16 @@ gt = synth.phantom(320, 320, 1000 + sl).abs()
 sol = get_solver(torch.device("cuda", 0), 320, 320, int(masks.shape[0]),
                  mlp_fp16=("bf16x2" if "--bf16x2" in sys.argv else "--mlp-fp16" in sys.argv))
 kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
-h = []
+K = next((int(x.split("=")[1]) for x in sys.argv if x.startswith("--seeds=")), 0)
+h, by_seed = [], {}
 for r in range(N):
-    ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, list(range(179, 200)))
+    seed = 2001 + r % K if K else 1337
+    ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, list(range(179, 200)), seed=seed)
     h.append(float(np.median(list(ps.values()))))
+    by_seed.setdefault(seed, []).append(h[-1])
+if K:
+    for sd in sorted(by_seed):
+        print("init seed %d: mean %.3f sd %.3f se %.3f (%d runs)" % (sd, *summarize(by_seed[sd]), len(by_seed[sd])))
+    print("mean over seeds of the per-seed means: %.3f" % np.mean([np.mean(v) for v in by_seed.values()]))
 print("slice", sl, [x for x in sys.argv if x.startswith("--")], N, "runs: median-of-last-21 PSNR mean %.3f sd %.3f se %.3f" % summarize(h),
       "median %.2f" % np.median(h), "deciles", np.round(np.quantile(h, np.linspace(0.1, 0.9, 9)), 2).tolist())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """tests/golden fixtures of the statistical parity tests from CPU-oracle runs made by tools/oracle_c2.py:
 
-    python tools/make_stats_fixtures.py /tmp/orc3
+    python tools/make_stats_fixtures.py /tmp/orc3 [/tmp/orc4]
 
   c2_oracle_200it_draws.npz        the reference script's own setting (iters = 200, /root/reference/src/test/
                                    test_immoco.py:65-72) at 320x320 / 10 groups: per slice (1, 4, 9) the loss and the
@@ -11,6 +11,9 @@
   c2_oracle_slice1_redraw1400.npz  the first 1400 iterations of the 3000-iteration solve of slice 1 with NEW summation
                                    orders drawn before EVERY step (OracleIMMoCo.redraw): 6 draws, loss and PSNR of every
                                    iteration
+  c2_oracle_slice1_initseeds.npz   (second directory) the first 1001 iterations of the same solve from OTHER initial
+                                   parameters (init seeds 2001...2008 instead of the reference's fixed 1337; orders
+                                   re-drawn every step): init_seed, redraw_seed, loss and PSNR of every iteration
 """
 import glob, os, sys
 import numpy as np
@@ -64,3 +67,17 @@ if ds:
           float((o[:, it.index(100):it.index(1500) + 1] < 38).mean()))
     print("redraw every-25 samples < 38 dB between 100 and 1375:", float((p[:, 100:1400:25] < 38).mean()),
           " sd of PSNR@1375 across draws: redraw %.3f fixed %.3f" % (p[:, 1375].std(ddof=1), o[:, it.index(1375)].std(ddof=1)))
+
+if len(sys.argv) > 2:
+    fs = sorted(glob.glob(os.path.join(sys.argv[2], "s1_init*.npz")))
+    ds = [np.load(f) for f in fs]
+    ds = [d for d in ds if int(d["iters_done"]) >= 1001 and int(d["sched_iters"]) == 3000 and int(d["redraw_seed"]) >= 0]
+    if ds:
+        seeds = np.array([int(d["init_seed"]) for d in ds], dtype=np.int32)
+        p = np.array([d["psnr_all"][:1001] for d in ds], dtype=np.float32)
+        np.savez_compressed(os.path.join(OUT, "c2_oracle_slice1_initseeds.npz"), init_seed=seeds,
+                            redraw_seed=np.array([int(d["redraw_seed"]) for d in ds], dtype=np.int32),
+                            loss=np.array([d["loss"][:1001] for d in ds], dtype=np.float32), psnr=p, slice_idx=np.int32(1))
+        plat = np.median(p[:, 600:1000:25], axis=1)
+        for sd in sorted(set(seeds.tolist())):
+            print(f"init seed {sd}: plateau medians (600..975 every 25) {np.round(plat[seeds == sd], 2).tolist()}")

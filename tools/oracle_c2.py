@@ -1,10 +1,13 @@
 """Run the CPU oracle on config C2 (320x320, 10 groups) for N iterations; log loss/PSNR; save npz.
 
-    python tools/oracle_c2.py <slice_idx> <iters> <out.npz> [order] [threads] [sched_iters] [redraw_seed]
+    python tools/oracle_c2.py <slice_idx> <iters> <out.npz> [order] [threads] [sched_iters] [redraw_seed] [init_seed]
 
 `redraw_seed` >= 0: draw NEW summation orders before EVERY step (OracleIMMoCo.redraw: hash-grid backward block
 order, MLP batch row order, motion-group order) from numpy's default_rng(redraw_seed) - the per-step analogue of
 what nondeterministic atomics do; -1 (default) keeps the single fixed `order` for the whole trajectory.
+
+`init_seed` (default 1337, the reference's fixed tcnn seed): seed of the initial parameters of both networks
+(miccai24_immoco_amd's init_params(seed, seed) draws the same values).
 
 `sched_iters` (default: iters) is the length of the solve whose lambda_GE schedule is used: `401 ... 3000` records
 the first 401 iterations of a 3000-iteration solve (a draw of the metric's trajectory), not a 401-iteration solve.
@@ -25,14 +28,15 @@ order = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 threads = int(sys.argv[5]) if len(sys.argv) > 5 else int(os.environ.get("ORACLE_THREADS", "4"))
 sched_iters = int(sys.argv[6]) if len(sys.argv) > 6 else iters
 redraw_seed = int(sys.argv[7]) if len(sys.argv) > 7 else -1
+init_seed = int(sys.argv[8]) if len(sys.argv) > 8 else 1337
 rng = np.random.default_rng(redraw_seed) if redraw_seed >= 0 else None
 torch.set_num_threads(threads)
 s = synth_cpu.make_slice(320, 320, 10, idx)
 masks = orc.extract_movement_groups(s["lines"], make_list=True)
 gt = s["gt"].abs()
 model = orc.OracleIMMoCo(masks,
-                         image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, bwd_order=order),
-                         motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, bwd_order=order))
+                         image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, seed=init_seed, bwd_order=order),
+                         motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, seed=init_seed, bwd_order=order))
 k = s["kspace"]
 kin = k.div(k.abs().max()).mul(16000).clone()
 opt = torch.optim.Adam([{"params": model.motion_inr.parameters(), "lr": 1e-2}, {"params": model.image_inr.parameters(), "lr": 1e-2}])
@@ -55,6 +59,6 @@ for j in range(iters):
     if j % 100 == 0 or j == iters - 1:
         np.savez_compressed(out, image=ip.detach().numpy(), kfm=kf.detach().numpy(), loss=np.array(hist, dtype=np.float64),
                             psnr_iters=np.array(list(psnrs.keys())), psnr=np.array(list(psnrs.values())), slice_idx=idx,
-                            iters=iters, sched_iters=sched_iters, iters_done=j + 1, order=order, threads=threads, redraw_seed=redraw_seed,
+                            iters=iters, sched_iters=sched_iters, iters_done=j + 1, order=order, threads=threads, redraw_seed=redraw_seed, init_seed=init_seed,
                             psnr_all=np.array(psnr_all, dtype=np.float32),
                             kspace=k.numpy(), lines=s["lines"].numpy(), n_groups=int(masks.shape[0]))
