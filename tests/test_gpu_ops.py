@@ -1533,7 +1533,7 @@ def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
     per init seed: 0 % for seeds 2002 / 2003 / 2006, 46 % and 58 % for 2005 and 2004; for seed 1337: matrix-core MLP
     kernels 25 %, the VALU kernels 11 %, the same kernels on one stream 38 %, oracle draws 1 of 19), so HIP and the
     oracle are compared seed by seed: CPU-oracle draws of the first 1001 iterations from init seeds 2001...2008 with
-    summation orders re-drawn every step (tests/golden/c2_oracle_slice1_initseeds.npz, tools/oracle_c2.py) against 10 HIP
+    summation orders re-drawn every step (tests/golden/c2_oracle_slice1_initseeds.npz, tools/oracle_c2.py) against 7 HIP
     runs per seed from the SAME initial parameters (immoco_init_params is bit-identical to the oracle's init).  Per run:
     the median PSNR over iterations 600, 625, ..., 975."""
     pkg, L, orc = env
@@ -1550,18 +1550,18 @@ def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
     hip = {}
     for sd in seeds:
         hip[sd] = []
-        for _ in range(10):
+        for _ in range(7):
             ps, _ = hip_psnr_samples(sol, kin, cg, gt, 3000, grid, seed=sd)
             hip[sd].append(float(np.median([ps[t] for t in grid])))
     for sd in seeds:
         print("init seed %d: hip %s | oracle %s" % (sd, np.round(hip[sd], 2).tolist(), np.round(o_plat[o_seed == sd], 2).tolist()))
     LOW = 38.0
     robust = [sd for sd in seeds if min(hip[sd]) >= 38.5]
-    fragile = [sd for sd in seeds if sum(v < LOW for v in hip[sd]) >= 3]
-    print("robust seeds (no HIP run of 10 below 38.5 dB)", robust, "fragile seeds (>= 3 of 10 HIP runs below 38 dB)", fragile)
+    fragile = [sd for sd in seeds if sum(v < LOW for v in hip[sd]) >= 2]
+    print("robust seeds (no HIP run of 7 below 38.5 dB)", robust, "fragile seeds (>= 2 of 7 HIP runs below 38 dB)", fragile)
     assert len(robust) >= 1 and len(fragile) >= 1, (robust, fragile, hip)
     # (1) from an initialisation HIP finds robust the oracle sits ON the plateau too, at the same level (a seed with a
-    #     10-20 % low-run probability passes for robust in 10 runs now and then: one low oracle draw is tolerated)
+    #     10-20 % low-run probability passes for robust in 7 runs now and then: one low oracle draw is tolerated)
     o_rob = np.concatenate([o_plat[o_seed == sd] for sd in robust])
     assert int((o_rob < LOW).sum()) <= 1, (robust, o_rob)
     for sd in robust:
@@ -1579,8 +1579,7 @@ def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
     assert frac_o > frac_rest or len(o_fra) < 4, (frac_o, frac_rest)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x2", "f16mlp"])
-@pytest.mark.parametrize("slice_idx", [1, 4, 9])
+@pytest.mark.parametrize("slice_idx,mode", [(1, "f32"), (4, "f32"), (9, "f32"), (4, "bf16x2"), (4, "f16mlp"), (9, "f16mlp")])
 def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, golden, slice_idx, mode):
     """Parity at the reference's OWN operating point: `iters=200`, 320x320, 10 groups
     (/root/reference/src/test/test_immoco.py:65-72; lambda_GE is halved 95 times and never reaches 0) on three slices
