@@ -378,8 +378,8 @@ def main():
             labels = {0: "f32", 1: "f16mlp/f32acc", 2: "f32 (MLP products: bf16x2 split, f32 accumulate)"}
             notes = {0: "exact fp32 everywhere",
                      1: "both MLPs with fp16 operands, fp32 accumulation, fp16 activations between the kernels: tiny-cuda-nn's "
-                        "network precision (/root/reference/src/models/immoco.py:11-25,60-65); measurably below fp32 in PSNR at 200 "
-                        "iterations (up to -1.4 dB), not resolvable at 3000 (DESIGN.md 2.2, 2.3)",
+                        "network precision (/root/reference/src/models/immoco.py:11-25,60-65); PSNR statistics within +-0.5 dB of fp32 "
+                        "over eight initialisations, up to -1.4 dB at 200 iterations from the reference's one (DESIGN.md 2.2, 2.3)",
                      2: "every MLP matrix operand split into two bf16 terms (product error <= 2^-16.5), everything else fp32 "
                         "(DESIGN.md 4.3)"}
             out["other_precision"] = []
