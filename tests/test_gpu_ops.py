@@ -1664,12 +1664,12 @@ def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, gold
     assert abs(dl[0]) <= 3.0 * dl[1] + (0.05 if mode == "f32" else 0.35) * float(np.mean(o_loss)), (dl, h_loss, o_loss)
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16mlp", "bf16x2"])
-def test_reference_setting_200_iterations_over_initialisations(env, golden, mode):
-    """The same operating point (iters = 200, slice 4 - the slice with the widest spread) over EIGHT initialisations
-    instead of one: CPU-oracle draws from init seeds 2001 ... 2008 with summation orders re-drawn every step
-    (`s4_*_initseed` in tests/golden/c2_oracle_200it_draws.npz, two per seed) against 6 HIP runs per seed from the same
-    initial parameters.  The per-seed level is a property of the initialisation (HIP: 27.2 ... 33.4 dB), so
+@pytest.mark.parametrize("slice_idx,mode", [(4, "f32"), (4, "f16mlp"), (4, "bf16x2"), (9, "f32")])
+def test_reference_setting_200_iterations_over_initialisations(env, golden, slice_idx, mode):
+    """The same operating point (iters = 200; slice 4 - the slice with the widest spread - and slice 9) over EIGHT
+    initialisations instead of one: CPU-oracle draws from init seeds 2001 ... 2008 with summation orders re-drawn every
+    step (`s4_*_initseed`, `s9_*_initseed` in tests/golden/c2_oracle_200it_draws.npz, two per seed) against 6 HIP runs per
+    seed from the same initial parameters.  The per-seed level is a property of the initialisation (HIP: 27.2 ... 33.4 dB), so
       * seed by seed the HIP and oracle means agree within their noise: chi-square of the eight per-seed differences
         (pooled within-seed variances; the oracle has two draws per seed) is reported and bounded, and
       * the mean over seeds of (HIP per-seed mean - oracle per-seed mean) is zero within 3 standard errors + 0.3 dB
@@ -1682,16 +1682,16 @@ def test_reference_setting_200_iterations_over_initialisations(env, golden, mode
     from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
     from oracle import synth_cpu
     g = golden("c2_oracle_200it_draws")
-    if "s4_initseed" not in g:
-        pytest.skip("no init-seed draws of slice 4 in the fixture")
-    o_seed = g["s4_initseed"].astype(int)
-    o_med = np.median(g["s4_psnr_initseed"][:, 179:200].astype(np.float64), axis=1)
+    if f"s{slice_idx}_initseed" not in g:
+        pytest.skip(f"no init-seed draws of slice {slice_idx} in the fixture")
+    o_seed = g[f"s{slice_idx}_initseed"].astype(int)
+    o_med = np.median(g[f"s{slice_idx}_psnr_initseed"][:, 179:200].astype(np.float64), axis=1)
     seeds = sorted(set(o_seed.tolist()))
     assert len(seeds) >= 6 and all((o_seed == sd).sum() >= 2 for sd in seeds)
-    s_ = synth_cpu.make_slice(320, 320, 10, 4)
+    s_ = synth_cpu.make_slice(320, 320, 10, slice_idx)
     k, lines = s_["kspace"].cuda(), s_["lines"].cuda()
     masks = pkg.extract_movement_groups(lines, make_list=True)
-    gt = synth.phantom(320, 320, 1004).abs()
+    gt = synth.phantom(320, 320, 1000 + slice_idx).abs()
     sol = get_solver(torch.device("cuda", 0), 320, 320, int(masks.shape[0]), mlp_fp16={"f32": 0, "f16mlp": 1, "bf16x2": 2}[mode])
     kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
     samples = list(range(179, 200))
@@ -1701,7 +1701,7 @@ def test_reference_setting_200_iterations_over_initialisations(env, golden, mode
             ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, samples, seed=sd)
             hip[sd].append(float(np.median([ps[t] for t in samples])))
             if mode == "f32":      # identical start: the oracle's first loss from the same initial parameters
-                o0 = g["s4_loss_initseed"][o_seed == sd][0, 0]
+                o0 = g[f"s{slice_idx}_loss_initseed"][o_seed == sd][0, 0]
                 assert abs(loss[0] - o0) <= 5e-5 * o0, (sd, loss[0], o0)
     mh = np.array([np.mean(hip[sd]) for sd in seeds])
     mo = np.array([o_med[o_seed == sd].mean() for sd in seeds])
@@ -1711,7 +1711,7 @@ def test_reference_setting_200_iterations_over_initialisations(env, golden, mode
     delta = float((mh - mo).mean())
     se = float(np.sqrt(vh / (len(seeds) * n_h) + vo / (len(seeds) * n_o)))
     r = float(np.corrcoef(mh, mo)[0, 1])
-    print(f"slice 4, 200 iterations, {mode}: per-seed means hip {mh.round(2).tolist()} oracle {mo.round(2).tolist()}; "
+    print(f"slice {slice_idx}, 200 iterations, {mode}: per-seed means hip {mh.round(2).tolist()} oracle {mo.round(2).tolist()}; "
           f"within-seed sd hip {np.sqrt(vh):.2f} oracle {np.sqrt(vo):.2f}; mean over seeds of the difference {delta:.3f} +- {se:.3f}; "
           f"correlation of the per-seed means {r:.2f}")
     chi2 = float((((mh - mo) ** 2) / (vh / n_h + vo / np.array([(o_seed == sd).sum() for sd in seeds]))).sum())

@@ -8,8 +8,8 @@
                                    PSNR of EVERY iteration of 8 draws (fp32 summation orders 0, 1, 2, 3, 5, 7, 11, 13 of
                                    the hash-grid backward), plus a checksum of the input the draws were run on; for slice 1
                                    also 8 draws with summation orders re-drawn before every step (`*_redraw`); for
-                                   slice 4 (second directory) re-drawn-order draws from init seeds 2001...2008
-                                   (`s4_*_initseed`)
+                                   slices 4 and 9 (second directory) re-drawn-order draws from init seeds 2001...2008
+                                   (`s4_*_initseed`, `s9_*_initseed`)
   c2_oracle_slice1_redraw1400.npz  the first 1400 iterations of the 3000-iteration solve of slice 1 with NEW summation
                                    orders drawn before EVERY step (OracleIMMoCo.redraw): 6 draws, loss and PSNR of every
                                    iteration
@@ -48,20 +48,20 @@ for sl in (1, 4, 9):
     p = out[f"s{sl}_psnr"]
     print(f"slice {sl}: {len(ds)} draws, final PSNR {np.round(p[:, -1], 2)} mean {p[:, -1].mean():.3f} sd {p[:, -1].std(ddof=1):.3f}; "
           f"median of last 21: {np.round(np.median(p[:, 179:], axis=1), 2)}")
-if len(sys.argv) > 2 and "s4_loss" in out:
-    # slice 4, the 200-iteration schedule from OTHER initial parameters (init seeds 2001...2008, re-drawn orders)
-    rs = [np.load(f) for f in sorted(glob.glob(os.path.join(sys.argv[2], "s4_200_init*.npz")))]
+for sl in ((4, 9) if len(sys.argv) > 2 else ()):
+    # the 200-iteration schedule from OTHER initial parameters (init seeds 2001...2008, re-drawn orders)
+    rs = [np.load(f) for f in sorted(glob.glob(os.path.join(sys.argv[2], f"s{sl}_200_init*.npz")))]
     rs = [d for d in rs if int(d["iters_done"]) == 200 and int(d["sched_iters"]) == 200 and int(d["redraw_seed"]) >= 0]
-    if rs:
-        ref = np.load(sorted(glob.glob(os.path.join(src, "s4_200_o*.npz")))[0])
+    if rs and f"s{sl}_loss" in out:
+        ref = np.load(sorted(glob.glob(os.path.join(src, f"s{sl}_200_o*.npz")))[0])
         assert all(np.array_equal(d["kspace"], ref["kspace"]) for d in rs)
-        out["s4_initseed"] = np.array([int(d["init_seed"]) for d in rs], dtype=np.int32)
-        out["s4_psnr_initseed"] = np.array([d["psnr_all"] for d in rs], dtype=np.float32)
-        out["s4_loss_initseed"] = np.array([d["loss"] for d in rs], dtype=np.float32)
-        m = np.median(out["s4_psnr_initseed"][:, 179:], axis=1)
-        for sd in sorted(set(out["s4_initseed"].tolist())):
-            print(f"slice 4, init seed {sd}: median of last 21 {np.round(m[out['s4_initseed'] == sd], 2).tolist()}")
-        print("slice 4: mean over seeds of the per-seed means %.3f" % np.mean([m[out["s4_initseed"] == sd].mean() for sd in set(out["s4_initseed"].tolist())]))
+        out[f"s{sl}_initseed"] = np.array([int(d["init_seed"]) for d in rs], dtype=np.int32)
+        out[f"s{sl}_psnr_initseed"] = np.array([d["psnr_all"] for d in rs], dtype=np.float32)
+        out[f"s{sl}_loss_initseed"] = np.array([d["loss"] for d in rs], dtype=np.float32)
+        sd_, m = out[f"s{sl}_initseed"], np.median(out[f"s{sl}_psnr_initseed"][:, 179:], axis=1)
+        for sd in sorted(set(sd_.tolist())):
+            print(f"slice {sl}, init seed {sd}: median of last 21 {np.round(m[sd_ == sd], 2).tolist()}")
+        print(f"slice {sl}: mean over seeds of the per-seed means %.3f" % np.mean([m[sd_ == sd].mean() for sd in set(sd_.tolist())]))
 if out:
     np.savez_compressed(os.path.join(OUT, "c2_oracle_200it_draws.npz"), **out)
     print("c2_oracle_200it_draws.npz", os.path.getsize(os.path.join(OUT, "c2_oracle_200it_draws.npz")), "bytes")
