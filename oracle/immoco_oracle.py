@@ -266,11 +266,14 @@ class HashGridPlan:
     oracle iteration; checked against the torch path in tests/test_oracle_hashgrid.py).
     `bwd_order` selects the (deterministic) fp32 summation order of the C backward."""
 
-    def __init__(self, coords: torch.Tensor, geo: GridGeometry, bwd_order: int = 0):
+    def __init__(self, coords: torch.Tensor, geo: GridGeometry, bwd_order: int = 0, device=None):
         c = coords.detach().cpu().to(torch.float32).numpy()
         self.geo = geo
         self.n_points = c.shape[0]
         self.bwd_order = bwd_order
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self._dev_idx = None   # per-corner [N*L] int32 entry indices / [N, L, 1] weights on `device` (encode_device)
+        self._dev_w = None
         idx_all, w_all = [], []
         for l in range(geo.n_levels):
             idx, w = grid_corners(c, geo, l)
@@ -302,8 +305,29 @@ class HashGridPlan:
     def encode_c(self, table: torch.Tensor) -> torch.Tensor:
         return _EncodeC.apply(table, self)
 
+    def encode_device(self, table: torch.Tensor) -> torch.Tensor:
+        """The same expression as `encode_torch` evaluated by ATen on `table.device` (the DEVICE ORACLE, a
+        sampler for the statistical parity tests: it shares no kernel with libimmoco_hip.so).  One
+        `index_select` per corner: its autograd backward is `index_add_`, which ATen implements on the GPU
+        with fp32 atomicAdd in nondeterministic order - the natural model of tiny-cuda-nn's atomic scatter
+        (SURVEY A.5), where the CPU paths use one fixed (or per-step re-drawn) summation order."""
+        g = self.geo
+        if self._dev_idx is None or self._dev_idx[0].device != table.device:
+            idx = self.idx_lm.permute(1, 0, 2)                       # [N, L, C]
+            w = self.w_lm.permute(1, 0, 2)
+            C = idx.shape[2]
+            self._dev_idx = [idx[:, :, c].reshape(-1).contiguous().to(table.device) for c in range(C)]
+            self._dev_w = [w[:, :, c].contiguous().to(table.device).unsqueeze(-1) for c in range(C)]
+        enc = None
+        for ic, wc in zip(self._dev_idx, self._dev_w):
+            t = table.index_select(0, ic).view(self.n_points, g.n_levels, g.n_features) * wc
+            enc = t if enc is None else enc + t
+        return enc.reshape(self.n_points, g.n_levels * g.n_features)
+
     def encode(self, table: torch.Tensor, backend: str = "c") -> torch.Tensor:
         assert self.geo.n_features == 2
+        if table.device.type != "cpu":
+            return self.encode_device(table)
         if backend == "c" and table.dtype == torch.float32:
             return self.encode_c(table)
         return self.encode_torch(table)
@@ -413,8 +437,12 @@ class OracleINR(torch.nn.Module):
     first forward (the reference always passes the same grid)."""
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False,
-                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True):
+                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True, device=None):
         super().__init__()
+        # device != cpu: the DEVICE ORACLE (ATen kernels only; HashGridPlan.encode_device) - the fast sampler
+        # of the statistical parity fixtures (tools/device_oracle_sampler.py); validated against the CPU oracle
+        # by tests/test_gpu_ops.py::test_device_oracle_vs_cpu_oracle_teacher_forced
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.table_fp16 = table_fp16   # gather from an fp16 copy of the table (fp32 master, straight-through)
         self.mlp_fp16 = mlp_fp16       # fp16 MLP operands, fp32 accumulation (_MLPHalf): tcnn's network precision
         self.loss_scale = loss_scale
@@ -426,7 +454,7 @@ class OracleINR(torch.nn.Module):
         self.n_output_dims = n_output_dims
         self.seed = seed
         p = init_inr_params(self.geo, self.mlp, seed)
-        self.params = torch.nn.Parameter(torch.from_numpy(p))
+        self.params = torch.nn.Parameter(torch.from_numpy(p).to(self.device))
         self._plan: Optional[HashGridPlan] = None
         self._plan_key = None
         self._row_perm = None          # redraw(): row permutation of the MLP's batch (dW summation order)
@@ -446,6 +474,7 @@ class OracleINR(torch.nn.Module):
                 self._row_perm = (bp[:, None] * blk + torch.arange(blk)[None, :]).reshape(-1)
             else:
                 self._row_perm = torch.from_numpy(rng.permutation(n))
+            self._row_perm = self._row_perm.to(self.device)
 
     def split(self, params=None):
         p = self.params if params is None else params
@@ -458,7 +487,7 @@ class OracleINR(torch.nn.Module):
     def plan_for(self, x: torch.Tensor) -> HashGridPlan:
         key = (x.data_ptr(), tuple(x.shape))
         if self._plan is None or self._plan_key != key:
-            self._plan = HashGridPlan(x, self.geo, self.bwd_order)
+            self._plan = HashGridPlan(x, self.geo, self.bwd_order, device=self.device)
             self._plan_key = key
         return self._plan
 
@@ -556,14 +585,18 @@ def identity_grid(H: int, W: int) -> torch.Tensor:
 class OracleIMMoCo(torch.nn.Module):
     """src/models/immoco.py:56-113 with the INRs injected."""
 
-    def __init__(self, masks, image_inr=None, motion_inr=None, seed=1337):
+    def __init__(self, masks, image_inr=None, motion_inr=None, seed=1337, device=None):
         super().__init__()
-        self.image_inr = image_inr or OracleINR(2, 2, encoding_config, network_config, seed=seed)
-        self.motion_inr = motion_inr or OracleINR(3, 2, encoding_config, mot_network_config, seed=seed + 1)
-        self.masks = masks
+        # both INRs start from the SAME seed: tiny-cuda-nn's module default is seed=1337 for every module
+        # (immoco.py:60-65 pass none), and every fixture and the HIP path (immoco_init_params) use 1337 for both
+        self.image_inr = image_inr or OracleINR(2, 2, encoding_config, network_config, seed=seed, device=device)
+        self.motion_inr = motion_inr or OracleINR(3, 2, encoding_config, mot_network_config, seed=seed, device=device)
+        self.device = self.image_inr.device
+        assert self.motion_inr.device == self.device
+        self.masks = masks.to(self.device)
         self.num_movements, self.x, self.num_lines = masks.shape
-        self.identy_grid = identity_grid(self.x, self.num_lines)
-        self.input_grid = make_grids((self.num_movements, self.x, self.num_lines))
+        self.identy_grid = identity_grid(self.x, self.num_lines).to(self.device)
+        self.input_grid = make_grids((self.num_movements, self.x, self.num_lines)).to(self.device)
         self._group_perm = None
 
     def redraw(self, rng: np.random.Generator):
@@ -571,7 +604,7 @@ class OracleIMMoCo(torch.nn.Module):
         i.e. of the sum over groups in the backward of `repeat` (immoco.py:91)."""
         self.image_inr.redraw(rng)
         self.motion_inr.redraw(rng)
-        self._group_perm = torch.from_numpy(rng.permutation(self.num_movements))
+        self._group_perm = torch.from_numpy(rng.permutation(self.num_movements)).to(self.device)
 
     def forward(self):
         H, W, nM = self.x, self.num_lines, self.num_movements
@@ -606,10 +639,15 @@ def lambda_schedule(iters: int, lambda_ge: float) -> List[float]:
 
 def oracle_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, lambda_ge=1e-2,
                              seed=1337, model: Optional[OracleIMMoCo] = None, loss_hist: Optional[list] = None,
-                             norm_scale: float = 16000.0, lambda_rule: str = "immoco"):
-    """src/models/immoco.py:116-206 on the CPU (no .cuda()).  norm_scale=8000 and
-    lambda_rule="downstream" give the variant copy of src/test/test_immoco_downstream.py:150-152,188-189."""
-    model = model or OracleIMMoCo(masks, seed=seed)
+                             norm_scale: float = 16000.0, lambda_rule: str = "immoco", device=None,
+                             on_forward=None):
+    """src/models/immoco.py:116-206 on the CPU (no .cuda()) or, with `device` / a model built on one, on that
+    device with ATen kernels (the device oracle).  norm_scale=8000 and lambda_rule="downstream" give the variant
+    copy of src/test/test_immoco_downstream.py:150-152,188-189.  `on_forward(j, image_prior, loss)` is called
+    after every forward with detached tensors (per-iteration PSNR records without a host synchronisation);
+    `loss_hist` costs one synchronisation per iteration."""
+    model = model or OracleIMMoCo(masks, seed=seed, device=device)
+    kspace_corr = kspace_corr.to(model.device)
     scale = kspace_corr.abs().max()
     kspace_input = kspace_corr.div(scale).mul(norm_scale).clone().detach()
     opt = torch.optim.Adam([
@@ -623,6 +661,8 @@ def oracle_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
             + gradient_entropy_loss(image_prior).mul(lambda_ge)
         loss.backward()
         opt.step()
+        if on_forward is not None:
+            on_forward(j, image_prior.detach(), loss.detach())
         if loss_hist is not None:
             loss_hist.append(float(loss.item()))
         if lambda_rule == "immoco":

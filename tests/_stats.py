@@ -1,40 +1,3 @@
-"""Trajectory sampling of the HIP solver for the statistical parity tests and tools/diag_stats.py (harness code: it
-drives the product API only - `get_solver(...).solve` in segments - and never touches the oracle)."""
-import numpy as np
-import torch
-
-
-def hip_psnr_samples(sol, kin, col_group, gt_abs, sched_iters, samples, lr=1e-2, lambda_ge=1e-2, seed=1337):
-    """One HIP solve of `sched_iters` iterations' schedule, run in segments that END at every iteration in `samples`
-    (sorted, < sched_iters): returns ({iteration: PSNR of that iteration's forward image}, loss history up to the
-    last sample).  The solver returns the image of the LAST forward of a segment (immoco.py:203-206), and a
-    segment continues from the previous one's parameters and Adam moments (`step0`)."""
-    from miccai24_immoco_amd.models.immoco import lambda_schedule
-    from miccai24_immoco_amd.utils.evaluate import crop_psnr
-    lam = lambda_schedule(sched_iters, lambda_ge)
-    pi, pm = sol.init_params(seed, seed)
-    ai = torch.zeros(2 * pi.numel(), device=pi.device)
-    am = torch.zeros(2 * pm.numel(), device=pm.device)
-    done, out, losses = 0, {}, []
-    for t in sorted(samples):
-        n = t + 1 - done
-        assert n >= 1 and t < sched_iters
-        img, _, l = sol.solve(kin, col_group, pi, pm, ai, am, n, lr, lam[done:done + n], step0=done, want_loss=True)
-        out[int(t)] = crop_psnr(img.abs().cpu(), gt_abs)
-        losses.append(l.cpu().numpy())
-        done = t + 1
-    return out, np.concatenate(losses)
-
-
-def summarize(values):
-    """mean, sample standard deviation, standard error of a list of per-run statistics."""
-    v = np.asarray(values, dtype=np.float64)
-    sd = float(v.std(ddof=1)) if len(v) > 1 else 0.0
-    return float(v.mean()), sd, sd / np.sqrt(len(v))
-
-
-def delta_with_se(hip, oracle):
-    """(mean HIP - mean oracle, standard error of that difference, variance ratio HIP / oracle)."""
-    mh, sh, eh = summarize(hip)
-    mo, so, eo = summarize(oracle)
-    return mh - mo, float(np.hypot(eh, eo)), (sh * sh) / max(so * so, 1e-12)
+"""Kept for the tests' imports: the trajectory-sampling helpers live in the package (miccai24_immoco_amd/utils/sampling.py,
+harness code over the product API only)."""
+from miccai24_immoco_amd.utils.sampling import hip_psnr_samples, summarize, delta_with_se  # noqa: F401

@@ -734,6 +734,34 @@ def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K, loss_rtol=1e-4
     for name in ("img", "mot"):
         assert rep[name]["untouched_moved_by_hip"] == 0, (name, rep[name])
         assert rep[name]["max_oracle_step_where_hip_is_still"] <= still_tol, (name, rep[name])   # nothing beyond rounding
+    rep["_oracle_record"] = o
+    return rep
+
+
+def _device_oracle_step(orc, o, masks, K, loss_rtol=1e-5, grad_tol=1e-4, **mode):
+    """The DEVICE ORACLE (oracle/immoco_oracle.py with device="cuda": ATen kernels only, fp32 atomics in the
+    hash-grid backward; the sampler of tests/golden/c2_device_oracle_draws.npz) teacher-forced by the CPU oracle:
+    iteration K from the CPU oracle's parameters - loss within 1e-5, gradients within 1e-4 relative L2 and of the
+    largest entry.  It shares no kernel with libimmoco_hip.so."""
+    dev = torch.device("cuda", 0)
+    model = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, device=dev, **mode),
+                             motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, device=dev, **mode))
+    with torch.no_grad():
+        model.image_inr.params.copy_(o["before"]["img"][0])
+        model.motion_inr.params.copy_(o["before"]["mot"][0])
+    kf, ip = model()
+    loss = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(o["kin"].to(dev))) + orc.gradient_entropy_loss(ip) * o["lam"][K]
+    loss.backward()
+    rep = {"K": K, "loss_device": float(loss), "loss_cpu": o["loss"][K]}
+    e = float((ip.detach().cpu() - o["image"]).abs().max() / o["image"].abs().max())
+    for name, p in (("img", model.image_inr.params), ("mot", model.motion_inr.params)):
+        g, g_ref = p.grad.cpu(), o["grads"][name]
+        rep[name] = (float((g - g_ref).norm() / g_ref.norm()), float((g - g_ref).abs().max() / g_ref.abs().max()))
+    print("device oracle vs CPU oracle, teacher-forced:", rep, "image max rel", e)
+    assert abs(rep["loss_device"] - rep["loss_cpu"]) <= loss_rtol * abs(rep["loss_cpu"]), rep
+    assert e <= 1e-4, e
+    for name in ("img", "mot"):
+        assert rep[name][0] <= grad_tol and rep[name][1] <= grad_tol, (name, rep)
     return rep
 
 
@@ -749,6 +777,7 @@ def test_teacher_forced_late_state_96(env, K):
     s = synth_cpu.make_slice(96, 96, 3, 11)
     masks = orc.extract_movement_groups(s["lines"], make_list=True)
     rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 200, K)
+    _device_oracle_step(orc, rep["_oracle_record"], masks, K)        # the device oracle from the same handed-over state
     # measured on MI355X: gradient rel. L2 2.4e-6 / 3.9e-6 (K = 60) and 1.0e-5 / 1.4e-5 (K = 130), largest
     # parameter-update difference 4.4e-7 = 4e-5 * lr, no update off by more than 1e-3 * lr
     for name in ("img", "mot"):
@@ -843,6 +872,7 @@ def test_teacher_forced_state_c2_shape(env, K):
     masks = orc.extract_movement_groups(s["lines"], make_list=True)
     K = int(os.environ.get("IMMOCO_TF_K", str(K)))       # diagnostic override
     rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, K)
+    _device_oracle_step(orc, rep["_oracle_record"], masks, K)        # the sampler at K = 5 / 200 too
     # measured, K = 5: gradient rel. L2 6e-7 (image) / 7e-6 (motion), largest update difference 4.0e-6 = 4e-4 * lr;
     # K = 200: 2.7e-6 / 1.8e-5, update difference 2.5e-5 on 10 of 9.45 M entries (Adam turns a cancelling-sum gradient
     # into a +-lr step: a handful of entries may differ by a few 1e-3 * lr there)

@@ -238,3 +238,24 @@ def test_mlp_fp16_mode_rounds_what_tcnn_rounds():
     assert torch.equal(outs[1][1][:nw], outs[2][1][:nw])              # weight gradients do not see the denc rounding
     d_t = float((outs[1][1][nw:] - outs[2][1][nw:]).norm() / outs[2][1][nw:].norm())
     assert 0.0 < d_t < 2e-3, d_t                                       # table gradients do (2^-11 per contribution)
+
+
+def test_device_encode_expression_is_the_torch_expression():
+    """HashGridPlan.encode_device (the device oracle's encode: one index_select per corner, backward = index_add_) is
+    the same arithmetic as encode_torch; checked here on CPU tensors (forward bit-identical, gradient to summation
+    accuracy), on the device by the teacher-forced tests of tests/test_gpu_ops.py."""
+    geo = orc.geometry_from_config(3, orc.encoding_config)
+    x = orc.make_grids((3, 12, 10))
+    plan = orc.HashGridPlan(x, geo)
+    g = torch.Generator().manual_seed(5)
+    t0 = torch.randn(geo.n_entries, 2, generator=g).requires_grad_(True)
+    t1 = t0.detach().clone().requires_grad_(True)
+    e0, e1 = plan.encode_torch(t0), plan.encode_device(t1)
+    assert torch.equal(e0, e1)
+    d = torch.randn(e0.shape, generator=g)
+    (e0 * d).sum().backward()
+    (e1 * d).sum().backward()
+    assert (t0.grad - t1.grad).abs().max() <= 2e-5 * t0.grad.abs().max()
+    # default seeds: both INRs start from tiny-cuda-nn's module default 1337 (immoco.py:60-65)
+    m = orc.OracleIMMoCo(torch.zeros(1, 8, 8, dtype=torch.long))
+    assert m.image_inr.seed == m.motion_inr.seed == 1337
