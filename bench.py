@@ -15,9 +15,12 @@ CPU oracle's full 3000-iteration records were run on - so the line carries the m
 --workload c3: BASELINE config 3, a step = one batch of --batch slices of the C2 shape through
 immoco_solver_solve_batch; --workload c5: 640x640, 20 groups, fp16 tables (both informational lines).
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank solves its own
-K slices (weak scaling, no data-path collective); the only collective is the final
-gather of the images (outside the hot loop, inside the timed region).
+N > 1: one rank per GPU; every rank solves its own K slices (weak scaling, no data-path
+collective); the only collective is the final gather of the images (outside the hot loop,
+inside the timed region).  `python bench.py --gpus N` launches its own N ranks (a parent that
+never touches the GPU starts N fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, relays rank 0's line and fails if any child does); under an outer
+`torch.distributed.run` (WORLD_SIZE already set) it is simply one of the ranks.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -73,7 +76,7 @@ def algorithmic_bytes(solver, nM):
     }
 
 
-def cpu_baseline(iters_sample=10):
+def cpu_baseline(iters_sample=30):
     """The oracle (CPU restatement of the reference loop) on this box's host cores, config C2,
     a bounded sample of iterations; slices/s extrapolated to 3000 iterations."""
     from oracle import immoco_oracle as orc, synth_cpu
@@ -106,6 +109,68 @@ def cpu_baseline(iters_sample=10):
                       f"oracle, {dt:.2f} s/iter, extrapolated x3000 iterations"}
 
 
+def launch_ranks(n, argv):
+    """Parent of `python bench.py --gpus N` without an outer launcher: N child processes, one per GPU, over
+    127.0.0.1.  The parent makes no HIP / torch.cuda call and loads no library (a process that has initialised
+    the GPU must not be the one that forks the ranks); children inherit stdout / stderr, so rank 0's JSON line is
+    this command's.  Exit status: 0 iff every rank exits 0; the first failure terminates the other ranks (their
+    exact PIDs)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for other in alive:
+                    other.terminate()
+    return rc
+
+
+def dry_run(args):
+    """--dry-run: the rank plumbing of the N > 1 path on the CPU (`gloo`), no GPU, no HIP library: every rank
+    contributes K fake images of its own, the same barrier / MAX-over-ranks timing and the single gather run, rank
+    0 prints the line.  tests/test_bench_launcher.py drives it at N = 2."""
+    import torch.distributed as dist
+    from miccai24_immoco_amd.shard import gather_images
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    K = args.steps
+    t0 = time.perf_counter()
+    local = torch.stack([torch.full((4, 4), float(rank * K + j), dtype=torch.complex64) for j in range(K)])
+    allimgs = gather_images(local, K * world, dst=0 if args.gather == "rank0" else None)
+    dt = time.perf_counter() - t0
+    seen = dist.get_world_size() if dist.is_initialized() else 1
+    if dist.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ids = sorted({int(v.real) for v in allimgs[:, 0, 0]})
+        print(json.dumps({"metric": "dry-run (rank plumbing only, no GPU work)", "value": K * world / max(dt, 1e-9),
+                          "unit": "fake slices/s", "n_gpus": world, "n_ranks_seen": seen, "steps": K, "warmup": args.warmup,
+                          "images_gathered": int(allimgs.shape[0]), "image_ids": ids, "scaling": "weak",
+                          "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,7 +197,17 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="slices per batch (c3)")
     ap.add_argument("--lanes", type=int, default=1, help="slices in flight side by side (c3; 1 is fastest)")
     ap.add_argument("--pair", action="store_true", help="c3: two slices per graph, gathers serialised (batch_pair)")
+    ap.add_argument("--gather", choices=["all", "rank0"], default="all",
+                    help="final images to every rank (all_gather_into_tensor) or to rank 0 only (gather, what the C4 line needs)")
+    ap.add_argument("--cpu-iters", type=int, default=30, help="iterations of the cpu_baseline sample (SURVEY 8d: 30)")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only, on the CPU with gloo (no GPU, no HIP library)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))      # this process never touches the GPU
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')} (set by an outer launcher): the two must agree")
+    if args.dry_run:
+        return dry_run(args)
     args.mlp_fp16 = 2 if args.precision == "bf16x2" else int(bool(args.mlp_fp16 or args.precision == "f16mlp"))
     global H, W, N_MOVEMENTS
     if args.workload == "c5":
@@ -146,7 +221,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world} (set by an outer launcher): the two must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
@@ -214,7 +289,7 @@ def main():
     t0 = time.perf_counter()
     imgs = [im for j in range(K) for im in step(Wm + j)]
     local = torch.stack(imgs)
-    allimgs = gather_images(local, K * B * world)      # the single RCCL collective (final images)
+    allimgs = gather_images(local, K * B * world, dst=0 if args.gather == "rank0" else None)   # the single RCCL collective
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -240,8 +315,7 @@ def main():
             # within ~150 iterations (tools/diag_blowups.py), and PSNR oscillates with period 2 by +-1.5 dB, so single-run,
             # single-iteration PSNR says little: seven extra runs are sampled at 1350 ... 1450 (every 25 iterations, the
             # oracle records' grid; median per run = the lambda_GE > 0 checkpoint) and at the end, with standard errors.
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from _stats import hip_psnr_samples, summarize, delta_with_se
+            from miccai24_immoco_amd.utils.sampling import hip_psnr_samples, summarize, delta_with_se
             import numpy as np
             rec = np.load(os.path.join(fx, "c2_oracle_slice1_3000it.npz"))
             its = list(rec["oracle_psnr_iters"])
@@ -356,7 +430,8 @@ def main():
         out = {
             "metric": "slices/sec at 320x320, 10 motion groups, 3000 iters; PSNR delta vs ref" if args.workload != "c5"
             else "slices/sec at 640x640, 20 motion groups (BASELINE config 5; informational)",
-            "value": round(value, 5), "unit": "slices/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": round(value, 5), "unit": "slices/s", "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": K, "warmup": Wm,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {(False, 0): "f32", (True, 0): "f32+f16tab", (False, 1): "f16mlp/f32acc", (True, 1): "f16mlp+f16tab/f32acc",
@@ -401,7 +476,7 @@ def main():
                     "psnr_db": [round(crop_psnr(alt_imgs[j].abs().cpu(), tsl[j]["gt"].abs().cpu()), 3) for j in range(n_alt)],
                     "note": notes[mode] + "; same slices as the timed run, outside the timed region"})
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_iters)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -262,6 +262,9 @@ typedef struct immoco_solver_cfg {
                              four hash-grid gather kernels (motion encode forward / backward of either slice) are
                              chained by events so that never two of them run at once, while the rest of one slice
                              (MLPs, warp, FFTs, losses, Adam, image chain) runs beside the other slice's gather */
+  /* immoco_solver_create validates every field: mlp_fp16 in {0, 1, 2}, batch_pair in {0, 1}, serial_chains in
+     {0, 1, 2}, batch_lanes in 0..64.  mlp_fp16 and batch_pair were `reserved[2]` before round 3: callers must
+     zero-initialise the struct (IMMOCO_E_INVALID otherwise). */
 } immoco_solver_cfg;
 
 typedef struct immoco_solver* immoco_solver_t;

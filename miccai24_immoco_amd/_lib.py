@@ -14,7 +14,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libimmoco_hip.so")
+# IMMOCO_LIB_PATH: load another build of the same C-ABI (the diagnostics build `make -C csrc diag`, whose IMMOCO_*
+# A/B switches the shipped library does not contain)
+LIB_PATH = os.environ.get("IMMOCO_LIB_PATH") or os.path.join(_HERE, "csrc", "libimmoco_hip.so")
 _lock = threading.Lock()
 _lib = None
 

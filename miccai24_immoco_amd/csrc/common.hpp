@@ -3,9 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/immoco_hip.h"
+
+// A/B and diagnostics switches (IMMOCO_* environment variables: kernel variants, scheduling experiments, and a few
+// timing-only ablations that compute WRONG results).  Only a library built with -DIMMOCO_DIAG (`make diag` ->
+// libimmoco_hip_diag.so, never loaded by the package unless IMMOCO_LIB_PATH points at it) reads them; the shipped
+// libimmoco_hip.so reads no environment variable at all and always runs the defaults.
+#ifdef IMMOCO_DIAG
+static inline const char* immoco_diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* immoco_diag_env(const char*) { return nullptr; }
+#endif
 
 namespace immoco {
 

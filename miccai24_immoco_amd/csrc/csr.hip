@@ -482,7 +482,7 @@ static int csr_build_t(CsrPlan* pl, hipStream_t st) {
   dim3 grid((unsigned)cdiv(n, 256), lv.n_levels);
   // twin entries: 3-D lattice whose dim 0 is the slowest axis (m), small enough for the LDS table and
   // for the float-assisted index division of the kernel
-  pl->pair_merge = D == 3 && pl->axn[0] <= 256 && n < (1 << 24) && !getenv("IMMOCO_CSR_NO_TWIN");
+  pl->pair_merge = D == 3 && pl->axn[0] <= 256 && n < (1 << 24) && !immoco_diag_env("IMMOCO_CSR_NO_TWIN");
   if (pl->pair_merge) {
     const int nf = lv.n_levels * pl->axn[0];
     IMMOCO_CHECK_HIP(hipMalloc((void**)&pl->f0tab, (size_t)nf * sizeof(float)));
@@ -707,7 +707,7 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
   // A/B switch (environment, read once): IMMOCO_CSR_STREAM = plain | 1 (nt entry loads) | 2 (nt tile stores) | 3 (both,
   // the default)
   static const int nt = [] {
-    const char* e = getenv("IMMOCO_CSR_STREAM");
+    const char* e = immoco_diag_env("IMMOCO_CSR_STREAM");
     return (e && strcmp(e, "plain") == 0) ? 0 : (e && atoi(e) > 0 ? (atoi(e) & 7) : 3);   // 7 = 3 + the half-stream ablation
   }();
   // Three workgroups per CU instead of the four that 33 KB of LDS would allow (12 KB of unused dynamic LDS): fewer
@@ -715,7 +715,7 @@ int launch_csr_bwd(const CsrPlan* pl, const float* denc_level_major, float* dtab
   // CU: 0.438; graph iteration 1.337 -> 1.322), 320x320x20 0.837 -> 0.800, 256x256x8 0.252 -> 0.241, 160x160x10
   // unchanged; plans that run as several rounds (launches of 8 parts) lose instead - 480x480x10 1.25 -> 1.33,
   // 640x640x20 3.54 -> 3.65 - and keep four.  A/B switch (environment, read once): IMMOCO_CSR_PAD_LDS=<bytes>.
-  static const int pad_env = [] { const char* e = getenv("IMMOCO_CSR_PAD_LDS"); return e ? atoi(e) : -1; }();
+  static const int pad_env = [] { const char* e = immoco_diag_env("IMMOCO_CSR_PAD_LDS"); return e ? atoi(e) : -1; }();
   const int pad_lds = pad_env >= 0 ? pad_env : (pl->rounds.size() == 1 ? 12288 : 0);
   for (size_t r = 0; r < pl->rounds.size(); ++r) {
     const uint32_t first = pl->rounds[r].first, cnt = pl->rounds[r].second;

@@ -103,7 +103,7 @@ static int check_lattice(const Levels& lv, const Lattice& lat, int64_t n) {
 // Motion-grid forward at 320x320x10 on one box: plain 0.2667, sc1 0.2618, nt 0.2565 ms.
 static int enc_store_sc1() {
   static const int v = [] {
-    const char* e = getenv("IMMOCO_ENC_STORE");
+    const char* e = immoco_diag_env("IMMOCO_ENC_STORE");
     return (e && strcmp(e, "plain") == 0) ? 0 : (e && strcmp(e, "sc1") == 0) ? 1 : 2;
   }();
   return v;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_lat3_kernel(Levels lv, Latti
 // kernel.  A/B switch (environment, read once): IMMOCO_FWD_K = 1 | 2 | 4.
 static int fwd_points_per_thread(int64_t n) {
   static const int forced = [] {
-    const char* e = getenv("IMMOCO_FWD_K");
+    const char* e = immoco_diag_env("IMMOCO_FWD_K");
     const int k = e ? atoi(e) : 0;
     return (k == 1 || k == 2 || k == 4) ? k : 0;
   }();

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(BWD_THREADS) void mlp_bwd_kernel(
 // valu-motion restrict the switch to one direction or one network (hidden width 256 / 64).
 static bool use_valu_impl(bool bwd, int n_hidden) {
   static const unsigned v = [] {
-    const char* e = getenv("IMMOCO_MLP_IMPL");
+    const char* e = immoco_diag_env("IMMOCO_MLP_IMPL");
     if (!e) return 0u;
     if (strcmp(e, "valu") == 0) return 15u;
     if (strcmp(e, "valu-fwd") == 0) return 5u;

@@ -187,7 +187,7 @@ int launch_adam_blocks(float* p, float* g, int n_gparts, int64_t g_stride, float
   // Gradients, moments and parameters stream through once per iteration: non-temporal loads and stores (motion grid
   // 0.0775 -> 0.0706 ms, graph iteration -0.5 %).  A/B switch (environment, read once): IMMOCO_ADAM_NT = 0 | 1 (g, m,
   // v) | 3 (and the parameter store; default).
-  static const int adam_nt = [] { const char* e = getenv("IMMOCO_ADAM_NT"); return e ? atoi(e) : 3; }();
+  static const int adam_nt = [] { const char* e = immoco_diag_env("IMMOCO_ADAM_NT"); return e ? atoi(e) : 3; }();
   adam_blocks_kernel<<<n_wblocks + n_blocks, 256, 0, st>>>(p, g, n_gparts, g_stride, m, v, n_w / 4, n_wblocks, blocks,
                                                           sched, iter_dev, iter_off, beta1, beta2, eps,
                                                           reinterpret_cast<__half*>(shadow), adam_nt);

@@ -80,7 +80,7 @@ extern "C" int immoco_probe_gather(int64_t footprint_bytes, int32_t bytes_per_lo
   const unsigned grid = (unsigned)(n_lanes / 256);
   for (int r = 0; r <= repeats; ++r) {        // r == 0: warm-up
     if (r == 1) IMMOCO_CHECK_HIP(hipEventRecord(e0, st));
-    static const char* pat = getenv("IMMOCO_PROBE_PATTERN");
+    static const char* pat = immoco_diag_env("IMMOCO_PROBE_PATTERN");
     if (pat && bytes_per_load == 16)
       probe_hash_kernel<float4><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(table), mask, (float)atof(pat), out);
     else if (pat)

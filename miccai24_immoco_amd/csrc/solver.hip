@@ -132,7 +132,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // cfg.mlp_fp16: the encodings (and dL/d enc, scaled by tcnn's loss scale) live as packed halves, one 4-byte word
   // per (point, level), like tiny-cuda-nn's fp16 encoding output / dL/dinput: half the bytes for the two MLP
   // kernels and 4-byte gathers for the encode backward.  (The generic atomic scatter reads fp32: fp32 buffers then.)
-  static const bool act16_env = [] { const char* e = getenv("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
+  static const bool act16_env = [] { const char* e = immoco_diag_env("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
   const bool act16 = s->cfg.mlp_fp16 == 1 && !s->cfg.atomic_scatter && act16_env;
   const int64_t e_ps = act16 ? 1 : 2;                  // strides of the level-major encodings, in 4-byte words
   const int64_t e_ls_m = act16 ? NP : 2 * NP, e_ls_i = act16 ? P : 2 * P;
@@ -141,7 +141,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // The motion forward is captured FIRST: of the two root chains of the replayed graph, the one captured first starts
   // with the graph, the other one ~12 us later behind the runtime's internal fork - and the motion chain is the
   // critical one (the image chain has 0.27 ms of slack).  A/B switch (environment, read once): IMMOCO_FWD_ORDER=image.
-  static const bool image_first = [] { const char* e = getenv("IMMOCO_FWD_ORDER"); return e && strcmp(e, "image") == 0; }();
+  static const bool image_first = [] { const char* e = immoco_diag_env("IMMOCO_FWD_ORDER"); return e && strcmp(e, "image") == 0; }();
   auto push_motion_fwd = [&] {
   if (nM > 0) {
     st.push_back({"motion_encode_fwd", [=](hipStream_t q) {
@@ -205,7 +205,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // backward and Adam then start beside the motion grid's encode backward instead of queueing behind its 6000
   // workgroups.  A/B switch (environment, read once): IMMOCO_FORK=early|late.
   static const int fork_env = [] {
-    const char* e = getenv("IMMOCO_FORK");
+    const char* e = immoco_diag_env("IMMOCO_FORK");
     return !e ? -1 : (strcmp(e, "early") == 0 ? 1 : 0);
   }();
   const bool fork_early = fork_env >= 0 ? fork_env == 1 : false;   // measured slower in every mode
@@ -233,7 +233,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // (then it runs in the gather's tail: 453 us, and the image chain ends the iteration 48 us after the motion chain).
   // A/B switch (environment, read once): IMMOCO_FORK2=image|motion.
   static const int fork2_env = [] {
-    const char* e = getenv("IMMOCO_FORK2");
+    const char* e = immoco_diag_env("IMMOCO_FORK2");
     return !e ? -1 : (strcmp(e, "image") == 0 ? 1 : 0);
   }();
   const bool image_first2 = fork2_env >= 0 ? fork2_env == 1 : false;
@@ -387,11 +387,25 @@ std::vector<Step> arrange(const std::vector<Step>& all, Order o) {
 // until the whole device is idle: at the latest when RETIRED_MAX of them have piled up (a device synchronise: the
 // host is that far ahead of the GPU only in batch solves), and when the solver is destroyed or re-planned.
 constexpr size_t RETIRED_MAX = 16;
-void retire_graph(immoco_solver* s) {
-  for (hipGraphExec_t* g : {&s->gexec, &s->gexec2, &s->pg1, &s->pgk}) {
-    if (!*g) continue;
+// The single-slice graphs (gexec, gexec2; key gkey) and the pair graphs (pg1, pgk; key pkey) are cached
+// independently: a solve that needs a new capture retires only its own family, so an odd-B paired batch (pairs,
+// then one single solve) or alternating single / paired calls on one solver do not re-capture each other's graphs.
+enum : int { RETIRE_SINGLE = 1, RETIRE_PAIR = 2, RETIRE_ALL = 3 };
+void retire_graph(immoco_solver* s, int which = RETIRE_ALL) {
+  auto drop = [&](hipGraphExec_t* g) {
+    if (!*g) return;
     s->retired.emplace_back(*g, nullptr);
     *g = nullptr;
+  };
+  if (which & RETIRE_SINGLE) {
+    drop(&s->gexec);
+    drop(&s->gexec2);
+    s->gkey.clear();
+  }
+  if (which & RETIRE_PAIR) {
+    drop(&s->pg1);
+    drop(&s->pgk);
+    s->pkey.clear();
   }
 }
 void sweep_retired(immoco_solver* s, bool wait) {
@@ -503,6 +517,11 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   IMMOCO_REQUIRE(cfg->image_grid.dims == 2 && cfg->motion_grid.dims == 3, "solver_create: grids must be 2-D/3-D");
   IMMOCO_REQUIRE(cfg->image_grid.n_levels == 16 && cfg->motion_grid.n_levels == 16,
                  "solver_create: 16 levels x 2 features expected");
+  // the words that were `reserved` before round 3 must be zero or a documented value (include/immoco_hip.h)
+  IMMOCO_REQUIRE(cfg->mlp_fp16 >= 0 && cfg->mlp_fp16 <= 2, "solver_create: mlp_fp16 must be 0 (fp32), 1 (fp16 operands) or 2 (bf16x2), got %d", cfg->mlp_fp16);
+  IMMOCO_REQUIRE(cfg->batch_pair == 0 || cfg->batch_pair == 1, "solver_create: batch_pair must be 0 or 1, got %d", cfg->batch_pair);
+  IMMOCO_REQUIRE(cfg->serial_chains >= 0 && cfg->serial_chains <= 2, "solver_create: serial_chains must be 0, 1 or 2 (auto), got %d", cfg->serial_chains);
+  IMMOCO_REQUIRE(cfg->batch_lanes >= 0 && cfg->batch_lanes <= 64, "solver_create: batch_lanes out of range (%d)", cfg->batch_lanes);
   int rc;
   if ((rc = check_mlp_cfg(&cfg->image_mlp)) || (rc = check_mlp_cfg(&cfg->motion_mlp))) return rc;
   immoco_solver* s = new immoco_solver();
@@ -544,7 +563,7 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   // in one launch, each into its own partial gradient table (summed by Adam), further ones in following launches
   // (with cfg.mlp_fp16 dL/denc is stored as packed halves: half the bytes per point, half the parts - at 320x320x10
   // 2 parts instead of 4: encode backward 0.386 -> 0.374 ms, motion Adam 0.069 -> 0.054 ms, iteration 1.042 -> 1.020)
-  const bool act16_on = [] { const char* e = getenv("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
+  const bool act16_on = [] { const char* e = immoco_diag_env("IMMOCO_ACT16"); return !e || atoi(e) != 0; }();
   const int auto_parts = csr_auto_parts((int64_t)cfg->nM * cfg->H * cfg->W, cfg->mlp_fp16 == 1 && !cfg->atomic_scatter && act16_on ? 4 : 8);
   s->mot_parts = cfg->atomic_scatter ? 1 : (cfg->grad_parts > 0 ? cfg->grad_parts : auto_parts);
   s->mot_tables = std::min(s->mot_parts, 8);
@@ -723,7 +742,7 @@ int finish_slice(immoco_solver* w, hipStream_t q, const SliceArgs& a) {
 // root-fork delay and end-of-graph gap.  Measured at 320x320x10: 1.2513 -> 1.2495 ms per iteration (the gaps hide
 // behind the device-side queue).  A/B switch (environment, read once): IMMOCO_GRAPH_K (default 8; 1 = one per launch).
 int graph_k() {
-  static const int k = [] { const char* e = getenv("IMMOCO_GRAPH_K"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  static const int k = [] { const char* e = immoco_diag_env("IMMOCO_GRAPH_K"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   return k;
 }
 
@@ -741,7 +760,7 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
   if ((rc = prepare_slice(s, q, a, iters, lr, lambda_sched, step0))) return rc;
   Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, loss_hist};
   // rotated order (see arrange()): an A/B switch (IMMOCO_PIPELINE=1), OFF by default - measured slower
-  static const bool want_pipeline = getenv("IMMOCO_PIPELINE") != nullptr;
+  static const bool want_pipeline = immoco_diag_env("IMMOCO_PIPELINE") != nullptr;
   const bool pipelined = want_pipeline && s->cfg.nM > 0 && !s->cfg.serial_chains;
   const std::vector<Step> all = build_steps(s, b, true);
   const std::vector<Step> first = arrange(all, pipelined ? Order::First : Order::Classic);
@@ -755,7 +774,7 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
   // ~50 us tail and the join / tick / fork gaps off the critical path - and puts the tail (image encode backward,
   // image Adam) BESIDE the next motion encode forward, whose 4 MB level slices then fall out of the XCD L2s
   // (DESIGN.md 4.1): 1.254 -> 1.371 ms per iteration in fp32, 1.029 -> 1.070 with fp16 MLPs.
-  static const bool chain_iters = [] { const char* e = getenv("IMMOCO_CHAIN_ITERS"); return e && atoi(e) != 0; }();
+  static const bool chain_iters = [] { const char* e = immoco_diag_env("IMMOCO_CHAIN_ITERS"); return e && atoi(e) != 0; }();
   std::vector<Step> chained = first;
   for (Step& x : chained)
     if (strcmp(x.name, "tick") == 0) x.branch = 2;
@@ -784,7 +803,7 @@ int solve_impl(immoco_solver_t s, const float* kspace_in, const int32_t* col_gro
     sweep_retired(s, false);
     const bool want_k = !pipelined && GK > 1 && iters >= GK;
     if (!s->gexec || key != s->gkey || (pipelined && iters > 1 && !s->gexec2) || (want_k && !s->gexec2)) {
-      retire_graph(s);
+      retire_graph(s, RETIRE_SINGLE);
       capture(first, &s->gexec, 1);
       if (pipelined && iters > 1 && s->gexec) capture(steady, &s->gexec2, 1);
       if (want_k && s->gexec) capture(first, &s->gexec2, GK);   // classic order: gexec2 = GK iterations
@@ -919,12 +938,11 @@ int solve_pair(immoco_solver* A, immoco_solver* B, const SliceArgs& a, const Sli
                                     b.kin, b.cg, b.pi, b.pm, b.ai, b.am, b.loss, B->sched, B};
     sweep_retired(A, false);
     if (!A->pg1 || key != A->pkey || (iters >= GK && GK > 1 && !A->pgk)) {
-      retire_graph(A);
+      retire_graph(A, RETIRE_PAIR);
       capture(&A->pg1, 1);
       if (A->pg1 && GK > 1 && iters >= GK) capture(&A->pgk, GK);
       (void)hipGetLastError();
       A->pkey = key;
-      A->gkey.clear();   // retire_graph dropped the single-slice graphs too
     }
     graph_ok = A->pg1 != nullptr;
   }

@@ -493,7 +493,7 @@ int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, 
                            hipStream_t st) {
   const int64_t n = (int64_t)nM * H * W;
   if (n == 0) return IMMOCO_OK;
-  static const bool lane_merge_only = getenv("IMMOCO_WARP_BWD") && strcmp(getenv("IMMOCO_WARP_BWD"), "flat") == 0;
+  static const bool lane_merge_only = immoco_diag_env("IMMOCO_WARP_BWD") && strcmp(immoco_diag_env("IMMOCO_WARP_BWD"), "flat") == 0;
   if (!lane_merge_only) {
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     // enough workgroups to fill the chip: split the motion groups into chunks
@@ -501,7 +501,7 @@ int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, 
     // (the kernel is latency-bound: 320x320x10 with 10 / 5 / 3 / 2 / 1 motion groups per workgroup takes 0.063 / 0.061 /
     // 0.056 / 0.054 / 0.061 ms - more, shorter workgroups until the per-workgroup window flush dominates.  A/B switch
     // (environment, read once): IMMOCO_WARP_BLOCKS = minimum number of workgroups.)
-    static const int min_blocks = [] { const char* e = getenv("IMMOCO_WARP_BLOCKS"); return e ? atoi(e) : 2000; }();
+    static const int min_blocks = [] { const char* e = immoco_diag_env("IMMOCO_WARP_BLOCKS"); return e ? atoi(e) : 2000; }();
     while (chunks < nM && (int64_t)tiles_x * tiles_y * chunks < min_blocks) ++chunks;
     const int mpc = (nM + chunks - 1) / chunks;
     chunks = (nM + mpc - 1) / mpc;

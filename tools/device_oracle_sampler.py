@@ -48,10 +48,28 @@ def device_psnr(pred_abs, gt_abs):
     return 20.0 * torch.log10(1.0 / torch.sqrt(torch.mean((p - g) ** 2)))
 
 
-def one_draw(k, masks, gt, sched, run, seed, mlp_fp16, dev):
-    kw = dict(seed=seed, device=dev, mlp_fp16=mlp_fp16)
-    model = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, **kw),
+_MODELS = {}
+
+
+def fresh_model(masks, seed, mlp_fp16, dev):
+    """One model per (shape, seed, precision) and process: the coordinate plans (numpy hashing of 1 M points, seconds)
+    are built once, every draw restarts from the initial parameters."""
+    key = (tuple(masks.shape), seed, bool(mlp_fp16))
+    if key not in _MODELS:
+        kw = dict(seed=seed, device=dev, mlp_fp16=mlp_fp16)
+        m = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, **kw),
                              motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, **kw))
+        _MODELS[key] = (m, m.image_inr.params.detach().clone(), m.motion_inr.params.detach().clone())
+    m, pi0, pm0 = _MODELS[key]
+    with torch.no_grad():
+        m.image_inr.params.copy_(pi0)
+        m.motion_inr.params.copy_(pm0)
+    m.image_inr.params.grad = m.motion_inr.params.grad = None
+    return m
+
+
+def one_draw(k, masks, gt, sched, run, seed, mlp_fp16, dev):
+    model = fresh_model(masks, seed, mlp_fp16, dev)
     kin = (k / k.abs().max() * 16000).to(dev)
     lam = orc.lambda_schedule(sched, 1e-2)
     opt = torch.optim.Adam([{"params": model.motion_inr.parameters(), "lr": 1e-2},
