@@ -122,6 +122,13 @@ int immoco_mlp_bwd(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_
                    int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
                    const float* dout /*[n][n_out]*/, float* din, float* dw1, float* dw2,
                    void* stream);
+/* The same backward of the 256-wide net (the image INR's CutlassMLP, /root/reference/src/models/immoco.py:11-17,60-62)
+ * as the TWO kernels the fused solver runs beside the motion grid's encode backward: din (must NOT alias in) by one,
+ * dw1 / dw2 (accumulated) by the other.  n_hidden must be 256. */
+int immoco_mlp_bwd_split(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                         int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                         const float* dout /*[n][n_out]*/, float* din, float* dw1, float* dw2,
+                         void* stream);
 
 /* The same MLP in tiny-cuda-nn's OWN network precision (the reference instantiates FullyFusedMLP / CutlassMLP with
  * __half, /root/reference/src/models/immoco.py:11-25,60-65; tcnn torch binding: loss_scale 128): fp16 OPERANDS -

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "immoco_hashgrid_bwd": (C.c_int, [_GP, _P, _I64, _P, _I64, _I64, _P, _P]),
     "immoco_mlp_fwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "immoco_mlp_bwd": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "immoco_mlp_bwd_split": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "immoco_mlp_fwd_half": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
     "immoco_mlp_bwd_half": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _F, _P, _P, _P, _P]),
     "immoco_mlp_fwd_bf16x2": (C.c_int, [_MP, _P, _I64, _I64, _I64, _P, _P, _P, _P]),

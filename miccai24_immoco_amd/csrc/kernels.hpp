@@ -39,6 +39,13 @@ int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
                         const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                         hipStream_t st, int64_t dout_plane = 0);
 
+// split backward of the 256-wide net (mlp_mfma.hip): d enc (out of place) and dW1 / dW2 as two kernels that fit beside
+// the motion grid's encode backward
+int launch_mlp_bwd_denc(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
+                        const float* w2, const float* dout, float* din, hipStream_t st, int64_t dout_plane = 0);
+int launch_mlp_bwd_dw(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
+                      const float* w2, const float* dout, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane = 0);
+
 // mlp_f16.hip — tiny-cuda-nn's operand precision: fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16);
 // the backward scales dout by `scale` (tcnn's loss scale, 128) before rounding it to fp16
 // enc_half: the encoding (and dL/d enc, which stays scaled by `scale`) is stored as packed halves, one 4-byte word per
@@ -48,6 +55,12 @@ int launch_mlp_fwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, i
 int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,
                        const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
                        hipStream_t st, int64_t dout_plane, float scale, bool enc_half = false);
+
+// the 256-wide net's backward as two kernels (part 1: d enc, out of place; part 2: dW1 / dW2) that fit beside the motion
+// grid's encode backward
+int launch_mlp_bwd_f16_split(const immoco_mlp_cfg& cfg, int part, const float* in, int64_t ps, int64_t ls, int64_t n,
+                             const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
+                             hipStream_t st, int64_t dout_plane, float scale, bool enc_half = false);
 
 // mlp_bf16x2.hip - (nearly) fp32 accuracy on the 16-bit matrix cores: every operand split into two bf16 terms, three
 // MFMAs per product, fp32 everywhere else (relative product error <= 2^-16.5)
@@ -69,12 +82,31 @@ int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, 
                            const float* adj_slots, int nM, int H, int W, float* dimage, float* d_o,
                            hipStream_t st);
 
+// pruned path (warp.hip): the motion images' row DFT restricted to the k-space columns their group owns, fused into
+// the warp (forward) and into the warp backward (adjoint); zt is the transposed k-space [W][H]
+int launch_motion_warp_dft(const float* image, const float* o, const float* xs, const float* ys, int nM, int H, int W,
+                           const float* tw, const int32_t* cols, const int32_t* off, float* t_out, float* zt,
+                           hipStream_t st);
+int launch_motion_warp_bwd_dft(const float* image, const float* t, const float* xs, const float* ys, const float* zt_adj,
+                               const float* tw, const int32_t* cols, const int32_t* off, int nM, int H, int W,
+                               float* dimage_planar, float* d_o, hipStream_t st);
+
 // kspace.hip
 int fft2c(const float* in, float* out, int batch, int H, int W, int mode, hipStream_t st);
 int fft_exec_inplace(float* buf, int batch, int H, int W, bool inverse, hipStream_t st);  // raw, no shifts
 int fft_fwd_to_transposed(float* in, float* out_t, int B, int H, int W, hipStream_t st);      // -> [W][B][H]
 int fft_adj_from_transposed(float* in_t, float* out, int B, int H, int W, hipStream_t st);  // [W][B][H] ->
 int launch_transpose_c64(const float* in, float* out, int H, int W, hipStream_t st);
+// pruned path (one image): rows [H][W] -> [W][H]; columns in place on [W][H]; rows adjoint [W][H] -> [H][W]
+int fft_rows_fwd_to_t(float* in, float* out_t, int H, int W, hipStream_t st);
+int fft_cols_inplace_t(float* zt, int H, int W, bool inverse, hipStream_t st);
+int fft_rows_adj_from_t(float* in_t, float* out, int H, int W, hipStream_t st);
+// cols[off[g] .. off[g+1]) = k-space columns of group g (0 = unwarped image), g = 0..nM; off has nM + 2 entries
+int launch_build_col_lists(const int32_t* col_group, int nM, int W, int32_t* cols, int32_t* off, hipStream_t st);
+int launch_keep_group0_cols(const float* in_t, const int32_t* col_group, int nM, int H, int W, float* out_t, hipStream_t st);
+// dimage = dwarp + sign*adjoint slot 0 + lambda*dGE; dwarp (planar, filled by the warp backward) cleared
+int launch_image_grad_init_after_warp(const float* image, const float* adj_slot0, int H, int W, const float* lambda_sched,
+                                      const int32_t* iter_dev, float* loss_hist, float* dimage, float* dwarp, hipStream_t st);
 int launch_select_dc_seed_t(float* fft_t, const int32_t* col_group, const float* kin_t, int nM, int H, int W,
                             float* kout_t, float* loss_hist, const int32_t* iter_dev, hipStream_t st);
 int launch_kspace_select(const float* kall, const int32_t* col_group, int nM, int H, int W, float* kout,

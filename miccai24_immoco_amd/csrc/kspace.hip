@@ -133,6 +133,89 @@ int fft_adj_from_transposed(float* in_t, float* out, int B, int H, int W, hipStr
   return exec_c2c(sp.rows_in_t, in_t, out, HIPFFT_BACKWARD, st);
 }
 
+// ---- pieces of the same split transform for ONE image (pruned path of the solver, warp.hip: the motion images never
+// go through a full 2-D transform there; only the unwarped image's rows and the W selected k-space columns do)
+int fft_rows_fwd_to_t(float* in, float* out_t, int H, int W, hipStream_t st) {       // [H][W] -> [W][H], along W
+  SplitPlans sp;
+  int rc = get_split_plans(1, H, W, &sp);
+  if (rc) return rc;
+  return exec_c2c(sp.rows_out_t, in, out_t, HIPFFT_FORWARD, st);
+}
+int fft_cols_inplace_t(float* zt, int H, int W, bool inverse, hipStream_t st) {      // [W][H], along H, in place
+  SplitPlans sp;
+  int rc = get_split_plans(1, H, W, &sp);
+  if (rc) return rc;
+  return exec_c2c(sp.cols, zt, zt, inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD, st);
+}
+int fft_rows_adj_from_t(float* in_t, float* out, int H, int W, hipStream_t st) {     // [W][H] -> [H][W], along W, unnormalised inverse
+  SplitPlans sp;
+  int rc = get_split_plans(1, H, W, &sp);
+  if (rc) return rc;
+  return exec_c2c(sp.rows_in_t, in_t, out, HIPFFT_BACKWARD, st);
+}
+
+// Column lists of the line masks (immoco.py:109-111: k-space column c comes from image g(c), 0 = the unwarped one):
+// cols[off[g] .. off[g + 1]) = the columns of group g in increasing order, g = 0 .. nM.  One workgroup; W and nM are
+// a few hundred at most.
+__global__ __launch_bounds__(256) void build_col_lists_kernel(const int32_t* __restrict__ col_group, int nM, int W,
+                                                              int32_t* __restrict__ cols, int32_t* __restrict__ off) {
+  __shared__ int cnt[256], start[257];
+  const int g = threadIdx.x;   // one thread per group (nM <= 255, checked by the launcher)
+  int n = 0;
+  if (g <= nM)
+    for (int c = 0; c < W; ++c) {
+      int v = col_group[c];
+      v = v < 0 ? 0 : (v > nM ? 0 : v);
+      n += v == g;
+    }
+  cnt[g] = n;
+  __syncthreads();
+  if (g == 0) {
+    int run = 0;
+    for (int k = 0; k <= nM; ++k) {
+      start[k] = run;
+      run += cnt[k];
+    }
+    start[nM + 1] = run;
+  }
+  __syncthreads();
+  if (g <= nM + 1) off[g] = start[g];
+  if (g <= nM) {
+    int w = start[g];
+    for (int c = 0; c < W; ++c) {
+      int v = col_group[c];
+      v = v < 0 ? 0 : (v > nM ? 0 : v);
+      if (v == g) cols[w++] = c;
+    }
+  }
+}
+
+int launch_build_col_lists(const int32_t* col_group, int nM, int W, int32_t* cols, int32_t* off, hipStream_t st) {
+  IMMOCO_REQUIRE(nM >= 0 && nM <= 254, "column lists: at most 254 motion groups (got %d)", nM);
+  build_col_lists_kernel<<<1, 256, 0, st>>>(col_group, nM, W, cols, off);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+// out_t[c][r] = g(c) == 0 ? in_t[c][r] : 0   (adjoint seed of the unwarped image: its own columns only)
+__global__ __launch_bounds__(256) void keep_group0_cols_kernel(const float2* __restrict__ in_t,
+                                                               const int32_t* __restrict__ col_group, int nM, int H,
+                                                               int W, float2* __restrict__ out_t) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // = c * H + r
+  if (i >= (int64_t)H * W) return;
+  int g = col_group[(int)(i / H)];
+  g = g < 0 ? 0 : (g > nM ? 0 : g);
+  out_t[i] = g == 0 ? in_t[i] : make_float2(0.f, 0.f);
+}
+
+int launch_keep_group0_cols(const float* in_t, const int32_t* col_group, int nM, int H, int W, float* out_t,
+                            hipStream_t st) {
+  keep_group0_cols_kernel<<<(unsigned)cdiv((int64_t)H * W, 256), 256, 0, st>>>((const float2*)in_t, col_group, nM, H, W,
+                                                                              (float2*)out_t);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
 // out[c][r] = in[r][c]  (complex, once per solve: the measured k-space into / the result out of the layout above)
 __global__ __launch_bounds__(256) void transpose_c64_kernel(const float2* __restrict__ in, float2* __restrict__ out,
                                                             int H, int W) {
@@ -319,16 +402,18 @@ __device__ __forceinline__ float ge_dl(float g) {
 
 // MODE 0: op-level (weight passed by value; dimage accumulates)
 // MODE 1: solver (weight = lambda_sched[*iter]; dimage = sign*adj0 + weight*dGE written; loss_hist[*iter])
+// MODE 2: solver, pruned path: the warp backward ran BEFORE this kernel and added its share into the planar buffer
+//         `dwarp`; dimage = dwarp + sign*adj0 + weight*dGE, and dwarp is cleared for the next iteration
 template <int MODE>
 __global__ __launch_bounds__(256) void ge_loss_kernel(const float2* __restrict__ x, int H, int W, float weight,
                                                       const float* __restrict__ lambda_sched,
                                                       const int32_t* __restrict__ iter_dev,
                                                       const float2* __restrict__ adj0, float* __restrict__ loss,
-                                                      float2* __restrict__ dimage) {
+                                                      float2* __restrict__ dimage, float* __restrict__ dwarp = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n = (int64_t)H * W;
   int it = 0;
-  if (MODE == 1) {
+  if (MODE >= 1) {
     it = *iter_dev;
     weight = lambda_sched[it];
   }
@@ -362,8 +447,15 @@ __global__ __launch_bounds__(256) void ge_loss_kernel(const float2* __restrict__
         const float s = ((r + c) & 1) ? -1.f : 1.f;
         const float2 a = adj0[i];
         float* pl = reinterpret_cast<float*>(dimage);
-        pl[i] = a.x * s + weight * gx;
-        pl[n + i] = a.y * s + weight * gy;
+        if (MODE == 2) {
+          pl[i] = dwarp[i] + (a.x * s + weight * gx);
+          pl[n + i] = dwarp[n + i] + (a.y * s + weight * gy);
+          dwarp[i] = 0.f;
+          dwarp[n + i] = 0.f;
+        } else {
+          pl[i] = a.x * s + weight * gx;
+          pl[n + i] = a.y * s + weight * gy;
+        }
       }
     }
   }
@@ -386,6 +478,16 @@ int launch_image_grad_init(const float* image, const float* adj_slot0, int H, in
   ge_loss_kernel<1><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float2*)image, H, W, 0.f, lambda_sched,
                                                             iter_dev, (const float2*)adj_slot0, loss_hist,
                                                             (float2*)dimage);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_image_grad_init_after_warp(const float* image, const float* adj_slot0, int H, int W, const float* lambda_sched,
+                                      const int32_t* iter_dev, float* loss_hist, float* dimage, float* dwarp,
+                                      hipStream_t st) {
+  const int64_t n = (int64_t)H * W;
+  ge_loss_kernel<2><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float2*)image, H, W, 0.f, lambda_sched, iter_dev,
+                                                            (const float2*)adj_slot0, loss_hist, (float2*)dimage, dwarp);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

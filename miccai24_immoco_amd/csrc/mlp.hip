@@ -254,3 +254,16 @@ extern "C" int immoco_mlp_bwd(const immoco_mlp_cfg* cfg, const float* in, int64_
   return launch_mlp_bwd(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, dout, din, dw1, dw2,
                         as_stream(stream), 0);
 }
+
+extern "C" int immoco_mlp_bwd_split(const immoco_mlp_cfg* cfg, const float* in, int64_t in_point_stride,
+                                    int64_t in_level_stride, int64_t n, const float* w1, const float* w2,
+                                    const float* dout, float* din, float* dw1, float* dw2, void* stream) {
+  int rc = check_mlp_cfg(cfg);
+  if (rc) return rc;
+  IMMOCO_REQUIRE(n >= 0 && (n == 0 || (in && w1 && w2 && dout && din && dw1 && dw2)), "mlp_bwd_split: NULL buffer");
+  IMMOCO_REQUIRE(cfg->n_hidden == 256, "mlp_bwd_split: n_hidden must be 256 (got %d)", cfg->n_hidden);
+  IMMOCO_REQUIRE(in != din, "mlp_bwd_split: din must not alias in (the dW kernel reads the encoding after din is written)");
+  if ((rc = launch_mlp_bwd_denc(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, dout, din, as_stream(stream), 0)))
+    return rc;
+  return launch_mlp_bwd_dw(*cfg, in, in_point_stride, in_level_stride, n, w1, w2, dout, dw1, dw2, as_stream(stream), 0);
+}

@@ -205,12 +205,21 @@ __global__ __launch_bounds__(256) void mlp_fwd_f16_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // backward.  dout is scaled by `scale` (tcnn's loss scale) before it is rounded to fp16; d enc and the weight
 // gradients are unscaled in fp32 on the way out.
-template <int HID, int ACT, bool EH>
-__global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
-    const float* in /* may alias din */, int64_t ps, int64_t ls, int64_t n, const float* __restrict__ w1,
+// MODE 0: the whole backward in one kernel.  MODE 1 / 2 (round 4, the 256-wide net in the solver): the same arithmetic as
+// two kernels that fit BESIDE the motion grid's encode backward instead of one that needs a CU to itself -
+//   MODE 1: d enc only (no transposed products, no weight-gradient accumulators: 34 KB of LDS);
+//   MODE 2: dW1 / dW2 only, for the NJW hidden tiles blockIdx.y selects (grid.y = NJT / NJW): two accumulators instead
+//           of eight.  Every value is computed by the same instructions in the same order as in MODE 0.
+constexpr int F16_NJW = 2;
+template <int HID, int ACT, bool EH, int MODE = 0>
+__global__ __launch_bounds__(256, MODE == 0 ? (HID == 64 ? 2 : 1) : 3) void mlp_bwd_f16_kernel(
+    const float* in /* may alias din (MODE 0) */, int64_t ps, int64_t ls, int64_t n, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ dout, float* din, float* __restrict__ dw1,
     float* __restrict__ dw2, int64_t n_tiles, int64_t dout_plane, float scale) {
   constexpr int NJT = HID / 32;
+  constexpr int NJL = MODE == 2 ? F16_NJW : NJT;                   // hidden tiles this workgroup works on
+  constexpr int UNR = MODE == 1 ? 2 : NJL;                         // unroll factor of the loop over them
+  const int jt0 = MODE == 2 ? (int)blockIdx.y * F16_NJW : 0;       // first of them
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h8v* aw = reinterpret_cast<h8v*>(smem);                          // [NJT][2][64]
   h8v* awt = aw + NJT * 2 * 64;                                    // [NJT][2][64]
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
   unsigned char* img_d = wv + IMG_BYTES;       // dpre tile  [point][hidden of the current jt]
   unsigned char* img_h = wv + 2 * IMG_BYTES;   // h tile     [point][hidden of the current jt]
   _Float16* dm = reinterpret_cast<_Float16*>(wv + 3 * IMG_BYTES);  // [2][32]
-  build_w1_frags<HID>(w1, aw, awt, threadIdx.x);
+  build_w1_frags<HID>(w1, aw, MODE == 2 ? nullptr : awt, threadIdx.x);
   for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = rh(w2[i]);
   __syncthreads();
 
@@ -241,10 +250,10 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
                  (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
   };
 
-  f32x16 dw1t[NJT];   // dW1^T tiles (x scale): rows k (features), col = hidden jt*32 + r
+  f32x16 dw1t[MODE == 1 ? 1 : NJL];   // dW1^T tiles (x scale): rows k (features), col = hidden (jt0 + jl)*32 + r
   f32x16 dw2acc = {0.f};  // dW2 (x scale): row 2 jt + o, col = hidden r of tile jt
 #pragma unroll
-  for (int jt = 0; jt < NJT; ++jt) dw1t[jt] = (f32x16){0.f};
+  for (int jl = 0; jl < (MODE == 1 ? 1 : NJL); ++jl) dw1t[jl] = (f32x16){0.f};
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
   EncRaw<EH> nx;
@@ -272,29 +281,34 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
     if (t + n_waves < n_tiles) load_raw(t + n_waves);
     // ---- stage the enc tile ([point][feature], 16 bytes per step) and the dout tile ([o][point]) for the
     // transposed products
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's readers are done
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const uint4 q4 = *reinterpret_cast<const uint4*>(&eb[s]);
-      *reinterpret_cast<uint2*>(img_e + r * IMG_ROW + 32 * s + 16 * h) = make_uint2(q4.x, q4.y);
-      *reinterpret_cast<uint2*>(img_e + r * IMG_ROW + 32 * s + 16 * h + 8) = make_uint2(q4.z, q4.w);
-    }
-    if (h == 0) {
-      dm[r] = dpk[0];
-      dm[32 + r] = dpk[1];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // A operands of the transposed products (kept for all hidden tiles):
-    //   enc^T: row = feature r, k = points 16s + 8h + i;   dout^T: row o = r & 1, same k
     h8v ea[2], da[2];
+    if (MODE != 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's readers are done
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      ea[s] = tr_read8(img_e, s);
-      da[s] = *reinterpret_cast<const h8v*>(dm + (r & 1) * 32 + 16 * s + 8 * h);
+      for (int s = 0; s < 2; ++s) {
+        const uint4 q4 = *reinterpret_cast<const uint4*>(&eb[s]);
+        *reinterpret_cast<uint2*>(img_e + r * IMG_ROW + 32 * s + 16 * h) = make_uint2(q4.x, q4.y);
+        *reinterpret_cast<uint2*>(img_e + r * IMG_ROW + 32 * s + 16 * h + 8) = make_uint2(q4.z, q4.w);
+      }
+      if (h == 0) {
+        dm[r] = dpk[0];
+        dm[32 + r] = dpk[1];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // A operands of the transposed products (kept for all hidden tiles):
+      //   enc^T: row = feature r, k = points 16s + 8h + i;   dout^T: row o = r & 1, same k
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        ea[s] = tr_read8(img_e, s);
+        da[s] = *reinterpret_cast<const h8v*>(dm + (r & 1) * 32 + 16 * s + 8 * h);
+      }
     }
     f32x16 denc = {0.f};
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
+    // (MODE 1 keeps no per-tile register arrays, so it need not be unrolled 8 times: fully unrolled the compiler hoists
+    // every tile's fragment loads and spills 1.3 KB per lane at this kernel's 168-register budget)
+#pragma unroll UNR
+    for (int jl = 0; jl < NJL; ++jl) {
+      const int jt = jt0 + jl;
       // ---- L1: rows = hidden, col = point
       f32x16 pre = {0.f};
       pre = mfma16(aw[(jt * 2) * 64 + lane], eb[0], pre);
@@ -317,12 +331,13 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
         }
       }
       // d enc^T[k][p] += sum_j W1[j][k] dpre[j][p]: dpre from the registers (accumulator k order)
-      {
+      if (MODE != 2) {
         const h8v b0 = {dp[0][0], dp[0][1], dp[1][0], dp[1][1], dp[2][0], dp[2][1], dp[3][0], dp[3][1]};
         const h8v b1 = {dp[4][0], dp[4][1], dp[5][0], dp[5][1], dp[6][0], dp[6][1], dp[7][0], dp[7][1]};
         denc = mfma16(awt[(jt * 2) * 64 + lane], b0, denc);
         denc = mfma16(awt[(jt * 2 + 1) * 64 + lane], b1, denc);
       }
+      if (MODE == 1) continue;
       // ---- L2: transpose dpre and h through the per-wave images: registers 4a .. 4a+3 = hidden 8a + 4h + (0..3)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous hidden tile's transposed reads are done
 #pragma unroll
@@ -338,12 +353,12 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
       for (int s = 0; s < 2; ++s) {
         const h8v db = tr_read8(img_d, s), hb = tr_read8(img_h, s);
         const h8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        dw1t[jt] = mfma16(ea[s], db, dw1t[jt]);                // dW1^T[k][j] += sum_p enc[p][k] dpre[p][j]
+        dw1t[MODE == 1 ? 0 : jl] = mfma16(ea[s], db, dw1t[MODE == 1 ? 0 : jl]);   // dW1^T[k][j] += sum_p enc[p][k] dpre[p][j]
         dw2acc = mfma16(mine ? da[s] : zero, hb, dw2acc);       // dW2[o][j]   += sum_p dout[p][o] h[p][j]
       }
     }
     // ---- d enc: rows = feature (g&3) + 8(g>>2) + 4h, col = point
-    if (valid) {
+    if (MODE != 2 && valid) {
       const float inv = 1.f / scale;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -363,6 +378,7 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
       }
     }
   }
+  if (MODE == 1) return;
   // ---- flush the weight gradients once per WORKGROUP: the four waves park their tiles in their (now free) LDS
   // areas, every wave sums a quarter of the tile over the four copies and adds it with contiguous atomics
   const float inv = 1.f / scale;
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
     }
   };
 #pragma unroll
-  for (int jt = 0; jt < NJT; ++jt) flush_tile(dw1t[jt], dw1 + (size_t)jt * 1024, true, 1024);
+  for (int jl = 0; jl < (MODE == 1 ? 1 : NJL); ++jl) flush_tile(dw1t[jl], dw1 + (size_t)(jt0 + jl) * 1024, true, 1024);
   // dW2 accumulator: row 2 jt + o, col = hidden r  ->  parked [row][col]; rows >= 2 NJT are zero.  dW2 is
   // [o][HID]: two passes (o = 0, 1) over a de-interleaved view would need another tile; the 2 NJT x 32 values are
   // few, so they go out with one atomic each from the flat view
@@ -398,7 +414,8 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_f16_kernel(
 #pragma unroll
   for (int g = 0; g < 16; ++g) ft[drow16(g, h) * TL + r] = dw2acc[g];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * NJT * 32; idx += 256) {
+  for (int idx0 = threadIdx.x; idx0 < 2 * NJL * 32; idx0 += 256) {
+    const int idx = idx0 + 2 * jt0 * 32;   // rows 2 jt0 .. 2 (jt0 + NJL) - 1 belong to this workgroup's hidden tiles
     const int row = idx >> 5, col = idx & 31, off = row * TL + col;
     const float v = ((ft_all[off] + ft_all[WAVE_F + off]) + (ft_all[2 * WAVE_F + off] + ft_all[3 * WAVE_F + off])) * inv;
     unsafeAtomicAdd(dw2 + (row & 1) * HID + (row >> 1) * 32 + col, v);
@@ -449,6 +466,47 @@ static int launch_bwd_f16_t(const float* in, int64_t ps, int64_t ls, int64_t n, 
                                                           dout_plane, scale);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
+}
+
+// split backward of the 256-wide net: part 1 = d enc (din must not alias in), part 2 = dW1 / dW2
+template <int ACT, bool EH, int MODE>
+static int launch_bwd_f16_split_t(const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1, const float* w2,
+                                  const float* dout, float* din, float* dw1, float* dw2, hipStream_t st,
+                                  int64_t dout_plane, float scale) {
+  constexpr int HID = 256, NJT = HID / 32;
+  const int64_t n_tiles = cdiv(n, 32);
+  // MODE 1: W1 and W1^T fragments + W2; MODE 2: the same layout (only the W1 fragments are built) + the per-wave images
+  const size_t sm = MODE == 1 ? (size_t)NJT * 2 * 64 * 16 * 2 + (size_t)2 * HID * 4 : f16_bwd_smem(HID);
+  static bool attr_set = false;
+  if (!attr_set) {
+    IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_f16_kernel<HID, ACT, EH, MODE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv(n_tiles, 4), MODE == 1 ? 512 : 256), MODE == 2 ? NJT / F16_NJW : 1);
+  mlp_bwd_f16_kernel<HID, ACT, EH, MODE><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles,
+                                                                dout_plane, scale);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+int launch_mlp_bwd_f16_split(const immoco_mlp_cfg& cfg, int part, const float* in, int64_t ps, int64_t ls, int64_t n,
+                             const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
+                             hipStream_t st, int64_t dout_plane, float scale, bool enc_half) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(cfg.n_hidden == 256 && (part == 1 || part == 2), "mlp_bwd_f16_split: 256-wide net, part 1 or 2");
+  IMMOCO_REQUIRE(part == 2 || in != din, "mlp_bwd_f16_split: din must not alias in");
+  IMMOCO_REQUIRE(enc_half || ((ps % 2) == 0 && (ls % 2) == 0), "mlp input strides must be even");
+#define IMMOCO_SPLIT(A, M)                                                                                                 \
+  return enc_half ? launch_bwd_f16_split_t<A, true, M>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale)  \
+                  : launch_bwd_f16_split_t<A, false, M>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale)
+  if (cfg.activation == IMMOCO_ACT_TANH) {
+    if (part == 1) IMMOCO_SPLIT(IMMOCO_ACT_TANH, 1);
+    IMMOCO_SPLIT(IMMOCO_ACT_TANH, 2);
+  }
+  if (part == 1) IMMOCO_SPLIT(IMMOCO_ACT_RELU, 1);
+  IMMOCO_SPLIT(IMMOCO_ACT_RELU, 2);
+#undef IMMOCO_SPLIT
 }
 
 int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n,

@@ -395,6 +395,225 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split backward of the WIDE net (round 4): two kernels that each fit BESIDE the motion grid's encode backward
+// (csr_bwd_kernel<3>: 126 registers, 3 workgroups of 45 KB of LDS per CU) instead of one 448-register / 105 KB
+// kernel that needs a CU to itself and therefore starves there (0.50 ms beside the gather against 0.11 ms alone:
+// profiles/r03_iteration_timeline_f32.txt; the image chain ended 60-90 us after the motion chain).
+//   mlp_bwd_denc_kernel  d enc = W1^T . ((W2^T dout) * act'(pre))   -> what the image grid's encode backward waits for
+//                        (one wave per 32-point tile, as above; W1 / W1^T fragments in LDS: 66 KB, < 128 registers)
+//   mlp_bwd_dw_kernel    dW1, dW2: a wave owns ONE tile of 32 hidden units (grid.y = 2 halves x 4 waves) for ALL of the
+//                        workgroup's point tiles; pre' = enc . W1^T is computed with the point on the register index
+//                        and the hidden unit on the lane (layout 2 directly: operands swapped), so dpre' IS the B operand
+//                        of dW1^T = enc^T . dpre' with no transpose; dW2 = per-lane partial sums.  No weight fragments
+//                        in LDS (the wave's 32 x 32 slice of W1 lives in 16 registers): 20 KB of LDS.
+// Both recompute pre (128 MFMAs per tile each): together 512 MFMAs per tile - what the fused kernel spends too (its
+// dW2 goes through a 16-MFMA chain per hidden tile).  Same arithmetic per product as the fused kernel: d enc is
+// bit-identical, dW1 / dW2 differ in the order of the sum over points.
+template <int HID, int ACT>
+__global__ __launch_bounds__(256, 4) void mlp_bwd_denc_kernel(const float* __restrict__ in, int64_t ps, int64_t ls,
+                                                              int64_t n, const float* __restrict__ w1,
+                                                              const float* __restrict__ w2,
+                                                              const float* __restrict__ dout, float* __restrict__ din,
+                                                              int64_t n_tiles, int64_t dout_plane) {
+  constexpr int NJT = HID / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* aw = reinterpret_cast<float4*>(smem);                  // W1 fragments    [NJT][4][64]
+  float4* awt = aw + NJT * 4 * 64;                               // W1^T fragments  [NJT][4][64]
+  float* w2s = reinterpret_cast<float*>(awt + NJT * 4 * 64);     // [2][HID]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  build_weight_frags<HID>(w1, aw, awt, threadIdx.x);
+  for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = w2[i];
+  __syncthreads();
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
+    const int64_t p = t * 32 + r;
+    const bool valid = p < n;
+    const int64_t pc = valid ? p : n - 1;
+    const float mq = valid ? 1.f : 0.f;
+    float eb[16];
+    load_enc_b(in, ps, ls, p, n, h, eb);
+    float2 d;
+    if (dout_plane) {  // wave-uniform
+      d = make_float2(dout[pc] * mq, dout[dout_plane + pc] * mq);
+    } else {
+      const float2 dv = *reinterpret_cast<const float2*>(dout + pc * 2);
+      d = make_float2(dv.x * mq, dv.y * mq);
+    }
+    f32x16 denc = {0.f};
+#pragma unroll 2
+    for (int jt = 0; jt < NJT; ++jt) {
+      const f32x16 pre = pre_tile(aw, jt, lane, eb);
+      float dp[16];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float4 wa = *reinterpret_cast<const float4*>(w2s + jt * 32 + 8 * a + 4 * h);
+        const float4 wb = *reinterpret_cast<const float4*>(w2s + HID + jt * 32 + 8 * a + 4 * h);
+        const float was[4] = {wa.x, wa.y, wa.z, wa.w}, wbs[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          dp[4 * a + b] = fmaf(was[b], d.x, wbs[b] * d.y) * act_d<ACT>(act_f<ACT>(pre[4 * a + b]));
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 a = awt[(jt * 4 + g4) * 64 + lane];
+        denc = mfma32(a.x, dp[4 * g4], denc);
+        denc = mfma32(a.y, dp[4 * g4 + 1], denc);
+        denc = mfma32(a.z, dp[4 * g4 + 2], denc);
+        denc = mfma32(a.w, dp[4 * g4 + 3], denc);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int level = 4 * a + 2 * h;
+        *reinterpret_cast<float2*>(din + p * ps + (int64_t)level * ls) = make_float2(denc[4 * a], denc[4 * a + 1]);
+        *reinterpret_cast<float2*>(din + p * ps + (int64_t)(level + 1) * ls) =
+            make_float2(denc[4 * a + 2], denc[4 * a + 3]);
+      }
+    }
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 4) void mlp_bwd_dw_kernel(const float* __restrict__ in, int64_t ps, int64_t ls,
+                                                            int64_t n, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2,
+                                                            const float* __restrict__ dout, float* __restrict__ dw1,
+                                                            float* __restrict__ dw2, int64_t n_tiles,
+                                                            int64_t dout_plane) {
+  constexpr int HID = 256;
+  __shared__ __attribute__((aligned(16))) float te_all[4 * 32 * TLD];   // per wave: enc tile, rows = feature, cols = point
+  __shared__ __attribute__((aligned(16))) float dos_all[4 * 64];        // per wave: dout [32 points][2]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  float* te = te_all + wave * 32 * TLD;
+  float* dos = dos_all + wave * 64;
+  // One hidden tile of 32 units per wave (two such waves' worth of state - 64 units - spills at 128 registers):
+  // blockIdx.y selects the half of the hidden layer, the wave its tile; jt = 4 blockIdx.y + wave.
+  const int jt = 4 * (int)blockIdx.y + wave;
+  const int j = jt * 32 + r;
+  // B fragments of pre' = enc . W1^T for hidden unit j: bw[s] = W1[j][2 s + h]
+  float bw[16];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {   // 8 consecutive features per pair of 16-byte loads
+    const float4 q0 = *reinterpret_cast<const float4*>(w1 + j * 32 + 8 * s4);
+    const float4 q1 = *reinterpret_cast<const float4*>(w1 + j * 32 + 8 * s4 + 4);
+    bw[4 * s4] = h ? q0.y : q0.x;
+    bw[4 * s4 + 1] = h ? q0.w : q0.z;
+    bw[4 * s4 + 2] = h ? q1.y : q1.x;
+    bw[4 * s4 + 3] = h ? q1.w : q1.z;
+  }
+  const float w20 = w2[j], w21 = w2[HID + j];
+  f32x16 dw1t = {0.f};   // dW1^T tile: dw1t[g] = dW1[j][k = drow(g, h)]
+  float dw2l0 = 0.f, dw2l1 = 0.f;
+  // (no software prefetch of the next tile: with it the kernel spills at the 128 registers that let it share a SIMD
+  // with three encode-backward waves; four workgroups per CU hide the load latency instead)
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {   // all four waves walk the SAME tiles
+    const int64_t q = t * 32 + r;
+    const int64_t qc = q < n ? q : n - 1;
+    const float mq = q < n ? 1.f : 0.f;
+    float eb[16];
+    load_enc_b(in, ps, ls, q, n, h, eb);
+    float2 d;
+    if (dout_plane) {  // wave-uniform
+      d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
+    } else {
+      const float2 dv = *reinterpret_cast<const float2*>(dout + qc * 2);
+      d = make_float2(dv.x * mq, dv.y * mq);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's readers are done (per-wave tiles)
+    if (h == 0) *reinterpret_cast<float2*>(dos + 2 * r) = d;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) te[(2 * s + h) * TLD + r] = eb[s];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // pre'[point drow(g, h)][hidden r]: A = enc (row = point r, k = feature 2 s + h), B = W1^T (k, col = hidden r)
+    f32x16 pp = {0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) pp = mfma32(eb[s], bw[s], pp);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float2 dq = *reinterpret_cast<const float2*>(dos + 2 * drow(g, h));   // dout of point drow(g, h): broadcast
+      const float hh = act_f<ACT>(pp[g]);
+      dw2l0 = fmaf(hh, dq.x, dw2l0);
+      dw2l1 = fmaf(hh, dq.y, dw2l1);
+      pp[g] = fmaf(w20, dq.x, w21 * dq.y) * act_d<ACT>(hh);               // dpre'
+    }
+    // dW1^T[k][j] += sum_p enc[p][k] dpre'[p][j]: A = enc^T in accumulator-k order (enc[point drow(g,h)][feature r])
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 q4 = *reinterpret_cast<const float4*>(te + r * TLD + 8 * a + 4 * h);
+      dw1t = mfma32(q4.x, pp[4 * a], dw1t);
+      dw1t = mfma32(q4.y, pp[4 * a + 1], dw1t);
+      dw1t = mfma32(q4.z, pp[4 * a + 2], dw1t);
+      dw1t = mfma32(q4.w, pp[4 * a + 3], dw1t);
+    }
+  }
+  // ---- flush: the wave's [32 hidden][32 features] tile of dW1 through its LDS tile -> 256-byte contiguous atomics
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int g = 0; g < 16; ++g) te[r * TLD + drow(g, h)] = dw1t[g];   // [hidden r][feature k]
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int idx = k * 64 + lane;   // (hidden = idx >> 5, feature = idx & 31) of this 32 x 32 tile
+    unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, te[(idx >> 5) * TLD + (idx & 31)]);
+  }
+  dw2l0 += __shfl_xor(dw2l0, 32, 64);
+  dw2l1 += __shfl_xor(dw2l1, 32, 64);
+  if (h == 0) {
+    unsafeAtomicAdd(dw2 + j, dw2l0);
+    unsafeAtomicAdd(dw2 + HID + j, dw2l1);
+  }
+}
+
+static size_t denc_smem(int hid) { return (size_t)(hid / 32) * 4 * 64 * 16 * 2 + (size_t)2 * hid * 4; }
+
+// d enc only (din may NOT alias in: the dW kernel still needs the encoding)
+int launch_mlp_bwd_denc(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
+                        const float* w2, const float* dout, float* din, hipStream_t st, int64_t dout_plane) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+  IMMOCO_REQUIRE(cfg.n_hidden == 256 && in != din, "mlp_bwd_denc: the split backward is built for the 256-wide net, out of place");
+  const int64_t n_tiles = cdiv(n, 32);
+  // 2 workgroups per CU at most (66 KB of LDS each); a workgroup's fragment build is amortised over its tiles
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_tiles, 4), 512);
+  const size_t sm = denc_smem(256);
+#define IMMOCO_DENC(A)                                                                                               \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_denc_kernel<256, A>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));                   \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    mlp_bwd_denc_kernel<256, A><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, n_tiles, dout_plane);        \
+  } while (0)
+  if (cfg.activation == IMMOCO_ACT_TANH) IMMOCO_DENC(IMMOCO_ACT_TANH);
+  else IMMOCO_DENC(IMMOCO_ACT_RELU);
+#undef IMMOCO_DENC
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+// dW1 += ..., dW2 += ... (atomics into the caller's gradient buffers, like the fused kernel)
+int launch_mlp_bwd_dw(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
+                      const float* w2, const float* dout, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane) {
+  if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+  IMMOCO_REQUIRE(cfg.n_hidden == 256, "mlp_bwd_dw: the split backward is built for the 256-wide net");
+  const int64_t n_tiles = cdiv(n, 32);
+  // grid.y: the two halves of the hidden layer; every workgroup flushes 16 KB of atomics once
+  const dim3 grid((unsigned)std::min<int64_t>(n_tiles, 384), 2);
+  if (cfg.activation == IMMOCO_ACT_TANH)
+    mlp_bwd_dw_kernel<IMMOCO_ACT_TANH><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, dout, dw1, dw2, n_tiles, dout_plane);
+  else
+    mlp_bwd_dw_kernel<IMMOCO_ACT_RELU><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, dout, dw1, dw2, n_tiles, dout_plane);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
 static size_t fwd_smem(int hid) { return (size_t)(hid / 32) * 4 * 64 * 16 + (size_t)2 * hid * 4; }
 static size_t bwd_smem(int hid) {
   return (size_t)(hid / 32) * 4 * 64 * 16 * 2 + (size_t)2 * hid * 4 + 4 * 64 * 4 + (size_t)4 * 2 * 32 * TLD * 4;

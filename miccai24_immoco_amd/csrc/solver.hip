@@ -45,6 +45,11 @@ struct immoco_solver {
   int64_t n_params_img = 0, n_params_mot = 0;
   // device workspace
   float *enc_img = nullptr, *enc_mot = nullptr, *image = nullptr, *o_mot = nullptr, *t_mot = nullptr;
+  float* denc_img = nullptr;   // dL/d enc of the image INR (split wide-MLP backward: out of place, exact fp32 only)
+  // pruned path (warp.hip): twiddles e^{-2 pi i k / W}, the column lists of the line masks, the warp backward's share of dL/dimage
+  bool pruned = false;
+  float *tw = nullptr, *dimage_w = nullptr;
+  int32_t *pr_cols = nullptr, *pr_off = nullptr;
   float *fftbuf = nullptr, *dimage = nullptr, *grad_img = nullptr, *grad_mot = nullptr, *kout = nullptr;
   float *fft_t = nullptr, *kin_t = nullptr;  // transposed k-space [W][nM+1][H]; measured k-space [W][H] (kout too)
   float *sched = nullptr, *lambda_dev = nullptr;
@@ -87,6 +92,22 @@ struct immoco_solver {
 };
 
 namespace {
+
+// Exact-fp32 MLPs, 256-wide image net: its backward runs as two kernels that fit BESIDE the motion grid's encode
+// backward (mlp_mfma.hip: mlp_bwd_denc_kernel / mlp_bwd_dw_kernel) instead of one that needs a CU to itself.
+// (mlp_fp16 = 1: the same split of mlp_f16.hip's kernel; the bf16x2 mode keeps the fused kernel.)
+// IMMOCO_SPLIT_BWD=0 (diagnostics build only): the fused kernels of rounds 1-3.
+bool split_image_bwd(const immoco_solver_cfg& c) {
+  static const bool off = [] { const char* e = immoco_diag_env("IMMOCO_SPLIT_BWD"); return e && atoi(e) == 0; }();
+  return !off && (c.mlp_fp16 == 0 || c.mlp_fp16 == 1) && c.image_mlp.n_hidden == 256 && !c.atomic_scatter;
+}
+
+// Pruned path: the motion images' row transforms as direct DFTs of their own k-space columns, fused into the warp
+// kernels (warp.hip).  IMMOCO_PRUNED=0 (diagnostics build only) selects the full batched transforms of rounds 1-3.
+bool use_pruned(const immoco_solver_cfg& c) {
+  static const bool off = [] { const char* e = immoco_diag_env("IMMOCO_PRUNED"); return e && atoi(e) == 0; }();
+  return !off && c.nM > 0 && c.nM <= 254 && c.W <= 4096;
+}
 
 template <typename T>
 int dev_alloc(immoco_solver* s, T** p, int64_t count) {
@@ -172,6 +193,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   return launch_mlp_fwd(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->image, q);
                 }, 2});
   st.push_back({"image_to_fft_slot", [=](hipStream_t q) { return launch_image_to_slot(s->image, H, W, s->fftbuf, q); }, 2});
+  if (s->pruned)   // rows of the unwarped image -> every column of the transposed k-space Z (the warp overwrites its own)
+    st.push_back({"image_rows_fft", [=](hipStream_t q) { return fft_rows_fwd_to_t(s->fftbuf, s->fft_t, H, W, q); }, 2});
   };
   if (image_first) {
     push_image_fwd();
@@ -180,6 +203,22 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     push_motion_fwd();
     push_image_fwd();
   }
+  const bool pruned = s->pruned;
+  float* zt0 = s->fft_t + 2 * P;   // pruned path: the adjoint seed of the unwarped image (its own columns only), [W][H]
+  if (pruned) {
+    // warp + row DFT of every motion image's own columns -> Z; ONE column transform; the select is implicit
+    st.push_back({"motion_warp_dft", [=](hipStream_t q) {
+                    return launch_motion_warp_dft(s->image, s->o_mot, s->xs, s->ys, nM, H, W, s->tw, s->pr_cols, s->pr_off,
+                                                  s->t_mot, s->fft_t, q);
+                  }});
+    st.push_back({"fft_cols_fwd", [=](hipStream_t q) { return fft_cols_inplace_t(s->fft_t, H, W, false, q); }});
+    st.push_back({"select_dc_seed", [=](hipStream_t q) {   // one image per column: the kernel's nM = 0 case
+                    return launch_select_dc_seed_t(s->fft_t, b.col_group, b.kin, 0, H, W, s->kout, b.loss_hist,
+                                                   s->iter_dev, q);
+                  }});
+    if (!backward) return st;
+    st.push_back({"fft_cols_adjoint", [=](hipStream_t q) { return fft_cols_inplace_t(s->fft_t, H, W, true, q); }});
+  } else {
   if (nM > 0) {
     st.push_back({"motion_warp_fwd", [=](hipStream_t q) {
                     return launch_motion_warp_fwd(s->image, s->o_mot, s->xs, s->ys, nM, H, W, s->t_mot, slot1, q);
@@ -198,6 +237,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                   return launch_image_grad_init(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
                                                 b.loss_hist, s->dimage, q);
                 }});
+  }
   // Where the second fork sits.  "late" (exact-fp32 MLPs): after the motion MLP backward - the wide MLP backward
   // needs 448 registers and 105 KB of LDS there and cannot share a CU with anything, so it runs beside the
   // gather-bound encode backward (and starves: DESIGN.md 4.4).  "early" (fp16 MLPs): right after the warp backward -
@@ -211,6 +251,9 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   const bool fork_early = fork_env >= 0 ? fork_env == 1 : false;   // measured slower in every mode
   if (nM > 0) {
     st.push_back({"motion_warp_bwd", [=](hipStream_t q) {
+                    if (pruned)   // adjoint row DFT on the fly; dL/dimage share into dimage_w (summed by the late grad init)
+                      return launch_motion_warp_bwd_dft(s->image, s->t_mot, s->xs, s->ys, s->fft_t, s->tw, s->pr_cols,
+                                                        s->pr_off, nM, H, W, s->dimage_w, s->o_mot, q);
                     return launch_motion_warp_bwd(s->image, s->t_mot, s->xs, s->ys, slot1, nM, H, W, s->dimage,
                                                   s->o_mot, q);
                   }});
@@ -251,6 +294,34 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // (The image chain's MFMA kernel starves beside the motion grid's encode backward - 0.53 ms instead of 0.14 in
   // the rocprofv3 stats - and slows that gather from 0.45 to 0.58 ms; run BEFORE the fork instead, alone, the
   // iteration takes 1.435 ms instead of 1.351: the overlap is still worth more than it costs.)
+  if (pruned) {
+    // off the critical path: the unwarped image's adjoint rows and the gradient-entropy term start the image branch
+    st.push_back({"image_adjoint_rows", [=](hipStream_t q) {
+                    int rc = launch_keep_group0_cols(s->fft_t, b.col_group, nM, H, W, zt0, q);
+                    return rc ? rc : fft_rows_adj_from_t(zt0, s->fftbuf, H, W, q);
+                  }, 2});
+    st.push_back({"image_grad_init_ge_late", [=](hipStream_t q) {
+                    return launch_image_grad_init_after_warp(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
+                                                             b.loss_hist, s->dimage, s->dimage_w, q);
+                  }, 2});
+  }
+  if (split_image_bwd(s->cfg)) {
+    st.push_back({"image_mlp_bwd_denc", [=](hipStream_t q) {
+                    if (s->cfg.mlp_fp16)
+                      return launch_mlp_bwd_f16_split(s->cfg.image_mlp, 1, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->dimage,
+                                                      s->denc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16);
+                    return launch_mlp_bwd_denc(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->denc_img, q,
+                                               /*planar dimage*/ P);
+                  }, 2});
+    st.push_back({"image_mlp_bwd_dw", [=](hipStream_t q) {
+                    if (s->cfg.mlp_fp16)
+                      return launch_mlp_bwd_f16_split(s->cfg.image_mlp, 2, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->dimage,
+                                                      nullptr, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16);
+                    return launch_mlp_bwd_dw(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, g_w1i, g_w2i, q,
+                                             /*planar dimage*/ P);
+                  }, 2});
+    return;
+  }
   st.push_back({"image_mlp_bwd", [=](hipStream_t q) {
                   if (s->cfg.mlp_fp16 == 2)
                     return launch_mlp_bwd_bf16x2(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->enc_img,
@@ -270,8 +341,9 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     push_image_mlp_bwd();
   }
   st.push_back({"image_encode_bwd", [=](hipStream_t q) {
-                  if (s->plan_img) return launch_csr_bwd(s->plan_img, s->enc_img, g_tabi, 0, 1, q, act16, 1.f / TCNN_LOSS_SCALE);
-                  return launch_hashgrid_bwd(s->lv_img, nullptr, &li, P, s->enc_img, 2, 2 * P, g_tabi, q);
+                  const float* de = split_image_bwd(s->cfg) ? s->denc_img : s->enc_img;
+                  if (s->plan_img) return launch_csr_bwd(s->plan_img, de, g_tabi, 0, 1, q, act16, 1.f / TCNN_LOSS_SCALE);
+                  return launch_hashgrid_bwd(s->lv_img, nullptr, &li, P, de, 2, 2 * P, g_tabi, q);
                 }, 2});
   // optimizer param-group order of the reference: motion first, then image (immoco.py:149-154)
   if (nM > 0)
@@ -311,10 +383,11 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                 }});
   for (Step& x : st) {
     const std::string n = x.name;
-    x.group = (n == "image_encode_fwd" || n == "image_mlp_fwd" || n == "image_to_fft_slot") ? 0
+    x.group = (n == "image_encode_fwd" || n == "image_mlp_fwd" || n == "image_to_fft_slot" || n == "image_rows_fft") ? 0
               : (n == "motion_encode_fwd" || n == "motion_mlp_fwd")                             ? 1
               : n == "motion_encode_bwd"                                                        ? 3
-              : (n == "image_mlp_bwd" || n == "image_encode_bwd" || n == "adam_image")         ? 4
+              : (n == "image_mlp_bwd" || n == "image_mlp_bwd_denc" || n == "image_mlp_bwd_dw" || n == "image_encode_bwd" ||
+                 n == "adam_image" || n == "image_adjoint_rows" || n == "image_grad_init_ge_late")  ? 4
               : n == "tick"                                                                     ? 5
               : n == "adam_motion"                                                              ? 6
                                                                                                 : 2;
@@ -548,6 +621,7 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
     return rc;                            \
   }
   A(enc_img, 32 * s->P)
+  if (split_image_bwd(s->cfg)) A(denc_img, 32 * s->P)
   A(enc_mot, 32 * NPa)
   A(image, 2 * s->P)
   A(o_mot, 2 * NPa)
@@ -577,6 +651,13 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   A(xs, cfg->W)
   A(ys, cfg->H)
   A(ms, cfg->nM > 0 ? cfg->nM : 1)
+  s->pruned = use_pruned(*cfg);
+  if (s->pruned) {
+    A(tw, 2 * (int64_t)cfg->W)
+    A(dimage_w, 2 * s->P)
+    A(pr_cols, cfg->W)
+    A(pr_off, cfg->nM + 2)
+  }
 #undef A
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   // (a high- or low-priority side stream makes the iteration 7 % slower - 1.71 vs 1.60 ms - whichever way)
@@ -586,6 +667,17 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   if (e == hipSuccess) e = hipEventCreate(&s->ev_k1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
+  if (e == hipSuccess && s->pruned) {
+    std::vector<float> twh(2 * (size_t)cfg->W);
+    for (int k = 0; k < cfg->W; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)cfg->W;
+      twh[2 * k] = (float)cos(a);
+      twh[2 * k + 1] = (float)sin(a);
+    }
+    e = hipMemcpy(s->tw, twh.data(), twh.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(s->dimage_w, 0, (size_t)s->P * 8);
+    if (e == hipSuccess) e = hipMemset(s->pr_off, 0, (size_t)(cfg->nM + 2) * 4);
+  }
   if (e == hipSuccess) e = hipMemset(s->grad_img, 0, (size_t)s->n_params_img * 4);
   if (e == hipSuccess) e = hipMemset(s->grad_mot, 0, (size_t)s->mot_gstride * s->mot_tables * 4);
   if (e != hipSuccess) {
@@ -596,6 +688,12 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   // create the FFT plans now (rocFFT compiles kernels) so that solve() - and its stream capture - never does
   if ((rc = fft_fwd_to_transposed(s->fftbuf, s->fft_t, cfg->nM + 1, cfg->H, cfg->W, s->stream)) ||
       (rc = fft_adj_from_transposed(s->fft_t, s->fftbuf, cfg->nM + 1, cfg->H, cfg->W, s->stream))) {
+    immoco_solver_destroy(s);
+    return rc;
+  }
+  if (s->pruned && ((rc = fft_rows_fwd_to_t(s->fftbuf, s->fft_t, cfg->H, cfg->W, s->stream)) ||
+                    (rc = fft_cols_inplace_t(s->fft_t, cfg->H, cfg->W, false, s->stream)) ||
+                    (rc = fft_rows_adj_from_t(s->fft_t, s->fftbuf, cfg->H, cfg->W, s->stream)))) {
     immoco_solver_destroy(s);
     return rc;
   }
@@ -618,7 +716,9 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   }
   csr_plan_free(s->plan_img);
   csr_plan_free(s->plan_mot);
-  float* bufs[] = {s->xs, s->ys, s->ms, s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
+  if (s->pr_cols) hipFree(s->pr_cols);
+  if (s->pr_off) hipFree(s->pr_off);
+  float* bufs[] = {s->tw, s->dimage_w, s->denc_img, s->xs, s->ys, s->ms, s->enc_img, s->enc_mot, s->image, s->o_mot, s->t_mot, s->fftbuf, s->dimage,
                    s->kout,    s->fft_t,    s->kin_t,    s->grad_img, s->grad_mot, s->sched, s->lambda_dev};
   for (float* b : bufs)
     if (b) hipFree(b);
@@ -727,6 +827,7 @@ int prepare_slice(immoco_solver* w, hipStream_t q, const SliceArgs& a, int32_t i
   IMMOCO_CHECK_HIP(hipMemsetAsync(w->iter_dev, 0, 4 * sizeof(int32_t), q));
   if (a.loss) IMMOCO_CHECK_HIP(hipMemsetAsync(a.loss, 0, (size_t)iters * 4, q));
   if ((rc = refresh_shadows(w, a.pi, a.pm, q))) return rc;
+  if (w->pruned && (rc = launch_build_col_lists(a.cg, w->cfg.nM, w->cfg.W, w->pr_cols, w->pr_off, q))) return rc;
   return launch_transpose_c64(a.kin, w->kin_t, w->cfg.H, w->cfg.W, q);
 }
 
@@ -1093,6 +1194,7 @@ extern "C" int immoco_solver_forward(immoco_solver_t s, const int32_t* col_group
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   // kin only feeds the (unused) residual here: point it at kout itself
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
+  if (s->pruned && (rc = launch_build_col_lists(col_group, s->cfg.nM, s->cfg.W, s->pr_cols, s->pr_off, q))) return rc;
   Bind b{s->kout, col_group, const_cast<float*>(params_image), const_cast<float*>(params_motion),
          nullptr, nullptr, nullptr};
   std::vector<Step> steps = build_steps(s, b, false);
@@ -1126,6 +1228,7 @@ extern "C" int immoco_solver_profile(immoco_solver_t s, const float* kspace_in, 
   IMMOCO_CHECK_HIP(hipMemsetAsync(s->iter_dev, 0, 4 * sizeof(int32_t), q));
   IMMOCO_CHECK_HIP(hipStreamSynchronize(q));
   if ((rc = refresh_shadows(s, params_image, params_motion, q))) return rc;
+  if (s->pruned && (rc = launch_build_col_lists(col_group, s->cfg.nM, s->cfg.W, s->pr_cols, s->pr_off, q))) return rc;
   if ((rc = launch_transpose_c64(kspace_in, s->kin_t, s->cfg.H, s->cfg.W, q))) return rc;
   Bind b{s->kin_t, col_group, params_image, params_motion, adam_image, adam_motion, nullptr};
   std::vector<Step> steps = build_steps(s, b, true);

@@ -310,6 +310,367 @@ __global__ __launch_bounds__(256) void motion_warp_bwd_tiled_kernel(const float2
   }
 }
 
+// Round 4: the same kernel with the LDS window kept in 64-bit FIXED POINT.  tools/bench_lds_atomic.hip: ds_add_f32 costs
+// ~3 clocks per active lane per CU (193 per wave instruction) where an integer LDS atomic costs 8 per wave instruction,
+// and pass B issues 8.2 M float lane-atomics per launch at 320x320x10: 96 K clocks per CU = 0.046 of the kernel's
+// 0.051 ms.  Every contribution wgt * go (one fp32 rounding, as before) is scaled by a per-workgroup power of two -
+// 2^50 / (largest |adjoint| component of the workgroup's points, found in pass A) - rounded to an integer and added
+// with ds_add_u64; the window sum is therefore the EXACT sum of the fp32 products to 2^-51 of the workgroup's largest
+// term, independent of the order in which the lanes arrive (a float atomic rounds after every add), and is converted
+// back to fp32 once when the window is flushed.  Range: at most 256 x (motion groups per workgroup) contributions per
+// window cell, each below 2^tbits after scaling; the host picks tbits so that their sum stays below 2^62.
+constexpr int WIN_MAX64 = 2048;
+
+__global__ __launch_bounds__(256) void motion_warp_bwd_tiled_i64_kernel(const float2* __restrict__ img,
+                                                                        const float2* __restrict__ t_in,
+                                                                        const float* __restrict__ xs,
+                                                                        const float* __restrict__ ys,
+                                                                        const float2* __restrict__ adj, int nM, int H,
+                                                                        int W, int tiles_x, int m_per_chunk, int tbits,
+                                                                        float* __restrict__ dpl,
+                                                                        float2* __restrict__ d_o) {
+  __shared__ unsigned long long win[2 * WIN_MAX64];
+  __shared__ int bb[4];
+  __shared__ unsigned int amax_bits;
+  const int tid = threadIdx.x;
+  const int c = (blockIdx.x % tiles_x) * 16 + (tid & 15), r = (blockIdx.x / tiles_x) * 16 + (tid >> 4);
+  const bool inside = c < W && r < H;
+  const int m0 = blockIdx.y * m_per_chunk, m1 = min(nM, m0 + m_per_chunk);
+  const int64_t P = (int64_t)H * W;
+  if (tid == 0) {
+    bb[0] = bb[1] = 1 << 30;
+    bb[2] = bb[3] = -(1 << 30);
+    amax_bits = 0u;
+  }
+  __syncthreads();
+  const float gx0 = inside ? xs[c] : 0.f, gy0 = inside ? ys[r] : 0.f;
+  // ---- pass A: bounding box of the in-bounds taps, largest adjoint component
+  int mnx = 1 << 30, mny = 1 << 30, mxx = -(1 << 30), mxy = -(1 << 30);
+  float am = 0.f;
+  if (inside) {
+    for (int m = m0; m < m1; ++m) {
+      const int64_t i = ((int64_t)m * H + r) * W + c;
+      const float2 t = t_in[i];
+      const float2 a = adj[i];
+      am = fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y)));
+      const Taps tp = make_taps(t.x + gx0, t.y + gy0, H, W);
+      const int ax = max(tp.x0, 0), bx = min(tp.x0 + 1, W - 1), ay = max(tp.y0, 0), by = min(tp.y0 + 1, H - 1);
+      if (ax <= bx && ay <= by) {
+        mnx = min(mnx, ax);
+        mxx = max(mxx, bx);
+        mny = min(mny, ay);
+        mxy = max(mxy, by);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, o, 64));
+    mny = min(mny, __shfl_xor(mny, o, 64));
+    mxx = max(mxx, __shfl_xor(mxx, o, 64));
+    mxy = max(mxy, __shfl_xor(mxy, o, 64));
+    am = fmaxf(am, __shfl_xor(am, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    atomicMin(&bb[0], mnx);
+    atomicMin(&bb[1], mny);
+    atomicMax(&bb[2], mxx);
+    atomicMax(&bb[3], mxy);
+    atomicMax(&amax_bits, __float_as_uint(am));   // non-negative floats order like their bit patterns (NaN: largest)
+  }
+  __syncthreads();
+  const int wx0 = bb[0], wy0 = bb[1];
+  const int ww = bb[2] - bb[0] + 1, wh = bb[3] - bb[1] + 1;
+  const bool any = bb[2] >= bb[0] && bb[3] >= bb[1];
+  // scale = 2^(tbits - e) with 2^(e-1) <= amax < 2^e (tbits = 53 - log2(contributions a cell can receive), host); amax = 0, inf or NaN: the direct float atomics below keep the
+  // reference behaviour (zeros add nothing, inf / NaN propagate)
+  const unsigned int ab = amax_bits;
+  const int ex = (int)(ab >> 23) - 126;                     // frexp exponent of a normal float
+  const bool fixed_ok = ab >= 0x00800000u && ab < 0x7F800000u;
+  const bool use_lds = any && fixed_ok && (int64_t)ww * wh <= WIN_MAX64;
+  const int k = min(max(tbits - ex, -100), 100);
+  const float scale = __uint_as_float((unsigned int)(k + 127) << 23);
+  const int wn = use_lds ? ww * wh : 0;
+  for (int i = tid; i < 2 * wn; i += 256) win[i] = 0ull;
+  __syncthreads();
+  // ---- pass B
+  if (inside) {
+    for (int m = m0; m < m1; ++m) {
+      const int64_t i = ((int64_t)m * H + r) * W + c;
+      const float2 t = t_in[i];
+      const float s = ((r + c) & 1) ? -1.f : 1.f;
+      const float2 a = adj[i];
+      const float2 go = make_float2(a.x * s, a.y * s);
+      const Taps tp = make_taps(t.x + gx0, t.y + gy0, H, W);
+      const float2 dg = sample_bwd(img, nullptr, tp, go, H, W);
+      d_o[i] = make_float2(dg.x * (1.f - t.x * t.x), dg.y * (1.f - t.y * t.y));
+      const float wgt[4] = {tp.nw, tp.ne, tp.sw, tp.se};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int xx = tp.x0 + (kk & 1), yy = tp.y0 + (kk >> 1);
+        if (inb(yy, xx, H, W)) {
+          const float vx = wgt[kk] * go.x, vy = wgt[kk] * go.y;
+          if (use_lds) {
+            const int li = (yy - wy0) * ww + (xx - wx0);
+            atomicAdd(&win[li], (unsigned long long)__float2ll_rn(vx * scale));
+            atomicAdd(&win[wn + li], (unsigned long long)__float2ll_rn(vy * scale));
+          } else {
+            unsafeAtomicAdd(dpl + (size_t)yy * W + xx, vx);
+            unsafeAtomicAdd(dpl + P + (size_t)yy * W + xx, vy);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const double inv = 1.0 / (double)scale;
+  for (int i = tid; i < wn; i += 256) {
+    const long long sre = (long long)win[i], sim = (long long)win[wn + i];
+    const size_t g = (size_t)(wy0 + i / ww) * W + wx0 + i % ww;
+    if (sre != 0) unsafeAtomicAdd(dpl + g, (float)((double)sre * inv));
+    if (sim != 0) unsafeAtomicAdd(dpl + P + g, (float)((double)sim * inv));
+  }
+}
+
+// ---- pruned path (round 4; SURVEY a9, reference src/models/immoco.py:97-111) ------------------------------------
+// K = FFT(image) (1 - sum_m mask_m) + sum_m FFT(warp_m) mask_m with column-constant masks: of the nM 2-D transforms of
+// the motion images only the k-space columns c with g(c) = m are ever used - W columns in all, whatever nM.  The row
+// transform (along W) of motion image m is therefore evaluated as a DIRECT DFT for its own columns only, fused into
+// the warp: Z[c][r] = sum_w warp_m[r][w] (-1)^(r+w) e^{-2 pi i w c / W}, written straight into the transposed
+// k-space Z[W][H]; one batched column transform of W columns (rocFFT) finishes ALL images at once, and the select is
+// implicit.  The adjoint runs backwards: column transform, then adj_m[r][w] = sum_{c in C_m} Zadj[c][r] e^{+2 pi i w c / W}
+// evaluated inside the warp backward.  Per iteration this replaces 10 of 11 2-D transforms each way and the 8 MB
+// warp-output / adjoint-input round trips by W^2 H complex multiply-adds (0.26 GFLOP at 320 x 320, whatever the masks).
+constexpr int DFT_ROWS = 4;   // rows of one motion image per workgroup of the forward kernel
+
+__global__ __launch_bounds__(256) void motion_warp_dft_kernel(const float2* __restrict__ img, const float2* __restrict__ o,
+                                                              const float* __restrict__ xs, const float* __restrict__ ys,
+                                                              int H, int W, const float2* __restrict__ tw_g,
+                                                              const int32_t* __restrict__ cols,
+                                                              const int32_t* __restrict__ off,
+                                                              float2* __restrict__ t_out, float2* __restrict__ zt) {
+  extern __shared__ float2 sm[];
+  float2* v = sm;                      // [DFT_ROWS][W] warped, sign-modulated rows
+  float2* tw = sm + DFT_ROWS * W;      // [W] e^{-2 pi i k / W}
+  const int m = blockIdx.y, r0 = blockIdx.x * DFT_ROWS, tid = threadIdx.x;
+  for (int idx = tid; idx < DFT_ROWS * W; idx += 256) {
+    const int rr = idx / W, w = idx - rr * W, r = r0 + rr;
+    float2 val = make_float2(0.f, 0.f);
+    if (r < H) {
+      const int64_t i = ((int64_t)m * H + r) * W + w;
+      const float2 ov = o[i];
+      const float2 t = make_float2(tanhf(ov.x), tanhf(ov.y));
+      t_out[i] = t;
+      const float2 sv = sample(img, make_taps(t.x + xs[w], t.y + ys[r], H, W), H, W);
+      const float sg = ((r + w) & 1) ? -1.f : 1.f;
+      val = make_float2(sv.x * sg, sv.y * sg);
+    }
+    v[idx] = val;
+  }
+  for (int k = tid; k < W; k += 256) tw[k] = tw_g[k];
+  __syncthreads();
+  const int c0 = off[m + 1], nc = off[m + 2] - c0;     // group m + 1 (0 is the unwarped image)
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int oi = wave; oi < DFT_ROWS * nc; oi += 4) {   // one (row, column) output per wave pass
+    const int rr = oi / nc, j = oi - rr * nc, r = r0 + rr;
+    const int c = cols[c0 + j];
+    const int step = (64 * c) % W;
+    int k = (lane * c) % W;
+    float ax = 0.f, ay = 0.f;
+    for (int w = lane; w < W; w += 64) {
+      const float2 x = v[rr * W + w], t = tw[k];
+      ax = fmaf(x.x, t.x, fmaf(-x.y, t.y, ax));
+      ay = fmaf(x.x, t.y, fmaf(x.y, t.x, ay));
+      k += step;
+      k -= k >= W ? W : 0;
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      ax += __shfl_xor(ax, sft, 64);
+      ay += __shfl_xor(ay, sft, 64);
+    }
+    if (lane == 0 && r < H) zt[(int64_t)c * H + r] = make_float2(ax, ay);
+  }
+}
+
+int launch_motion_warp_dft(const float* image, const float* o, const float* xs, const float* ys, int nM, int H, int W,
+                           const float* tw, const int32_t* cols, const int32_t* off, float* t_out, float* zt,
+                           hipStream_t st) {
+  if (nM == 0) return IMMOCO_OK;
+  dim3 grid((unsigned)cdiv(H, DFT_ROWS), (unsigned)nM);
+  const size_t smem = (size_t)(DFT_ROWS + 1) * W * sizeof(float2);
+  IMMOCO_REQUIRE(smem <= 64 * 1024, "motion_warp_dft: image width %d too large for the row tile", W);
+  motion_warp_dft_kernel<<<grid, 256, smem, st>>>((const float2*)image, (const float2*)o, xs, ys, H, W, (const float2*)tw,
+                                                  cols, off, (float2*)t_out, (float2*)zt);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
+// Backward: motion_warp_bwd_tiled_i64_kernel with the adjoint row DFT evaluated on the fly (16 x 16 pixel tile x a
+// chunk of at most two motion groups).  zc[rr][jj] stages Zadj[c_j][r0 + rr] of 32 columns at a time.
+constexpr int BWD_MPC = 2, BWD_CC = 32;
+
+__global__ __launch_bounds__(256) void motion_warp_bwd_dft_kernel(const float2* __restrict__ img,
+                                                                  const float2* __restrict__ t_in,
+                                                                  const float* __restrict__ xs,
+                                                                  const float* __restrict__ ys,
+                                                                  const float2* __restrict__ zt,
+                                                                  const float2* __restrict__ tw_g,
+                                                                  const int32_t* __restrict__ cols,
+                                                                  const int32_t* __restrict__ off, int nM, int H, int W,
+                                                                  int tiles_x, int tbits, float* __restrict__ dpl,
+                                                                  float2* __restrict__ d_o) {
+  __shared__ unsigned long long win[2 * WIN_MAX64];
+  __shared__ float2 zc[16][BWD_CC];
+  __shared__ int cl[BWD_CC];
+  __shared__ int bb[4];
+  __shared__ unsigned int amax_bits;
+  extern __shared__ float2 tw[];   // [W] e^{-2 pi i k / W}; the adjoint uses the conjugate
+  const int tid = threadIdx.x;
+  const int tc = tid & 15, tr = tid >> 4;
+  const int c = (blockIdx.x % tiles_x) * 16 + tc, r0 = (blockIdx.x / tiles_x) * 16, r = r0 + tr;
+  const bool inside = c < W && r < H;
+  const int m0 = blockIdx.y * BWD_MPC, m1 = min(nM, m0 + BWD_MPC);
+  const int64_t P = (int64_t)H * W;
+  if (tid == 0) {
+    bb[0] = bb[1] = 1 << 30;
+    bb[2] = bb[3] = -(1 << 30);
+    amax_bits = 0u;
+  }
+  for (int k = tid; k < W; k += 256) tw[k] = tw_g[k];
+  __syncthreads();
+  // ---- adjoint row DFT: a[mi] = sum_{c' in C_m} Zadj[c'][r] e^{+2 pi i c c' / W}  (c = this thread's pixel column)
+  float2 a[BWD_MPC];
+#pragma unroll
+  for (int mi = 0; mi < BWD_MPC; ++mi) {
+    a[mi] = make_float2(0.f, 0.f);
+    const int m = m0 + mi;
+    if (m >= m1) continue;                                  // workgroup-uniform
+    const int cb0 = off[m + 1], nc = off[m + 2] - cb0;
+    for (int cb = 0; cb < nc; cb += BWD_CC) {
+      const int ncc = min(BWD_CC, nc - cb);
+      __syncthreads();                                      // the previous chunk's readers are done
+      if (tid < ncc) cl[tid] = cols[cb0 + cb + tid];
+      for (int e = tid; e < 16 * ncc; e += 256) {
+        const int rr = e / ncc, jj = e - rr * ncc;
+        const int cc = cols[cb0 + cb + jj];
+        zc[rr][jj] = (r0 + rr) < H ? zt[(int64_t)cc * H + r0 + rr] : make_float2(0.f, 0.f);
+      }
+      __syncthreads();
+      if (inside) {
+        for (int jj = 0; jj < ncc; ++jj) {
+          const float2 z = zc[tr][jj], t = tw[(c * cl[jj]) % W];
+          // z * conj(t)
+          a[mi].x = fmaf(z.x, t.x, fmaf(z.y, t.y, a[mi].x));
+          a[mi].y = fmaf(z.y, t.x, fmaf(-z.x, t.y, a[mi].y));
+        }
+      }
+    }
+  }
+  const float gx0 = inside ? xs[c] : 0.f, gy0 = inside ? ys[r] : 0.f;
+  // ---- pass A: bounding box of the in-bounds taps, largest adjoint component
+  int mnx = 1 << 30, mny = 1 << 30, mxx = -(1 << 30), mxy = -(1 << 30);
+  float am = 0.f;
+  if (inside) {
+#pragma unroll
+    for (int mi = 0; mi < BWD_MPC; ++mi) {
+      const int m = m0 + mi;
+      if (m >= m1) continue;
+      const float2 t = t_in[((int64_t)m * H + r) * W + c];
+      am = fmaxf(am, fmaxf(fabsf(a[mi].x), fabsf(a[mi].y)));
+      const Taps tp = make_taps(t.x + gx0, t.y + gy0, H, W);
+      const int ax = max(tp.x0, 0), bx = min(tp.x0 + 1, W - 1), ay = max(tp.y0, 0), by = min(tp.y0 + 1, H - 1);
+      if (ax <= bx && ay <= by) {
+        mnx = min(mnx, ax);
+        mxx = max(mxx, bx);
+        mny = min(mny, ay);
+        mxy = max(mxy, by);
+      }
+    }
+  }
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, sft, 64));
+    mny = min(mny, __shfl_xor(mny, sft, 64));
+    mxx = max(mxx, __shfl_xor(mxx, sft, 64));
+    mxy = max(mxy, __shfl_xor(mxy, sft, 64));
+    am = fmaxf(am, __shfl_xor(am, sft, 64));
+  }
+  if ((tid & 63) == 0) {
+    atomicMin(&bb[0], mnx);
+    atomicMin(&bb[1], mny);
+    atomicMax(&bb[2], mxx);
+    atomicMax(&bb[3], mxy);
+    atomicMax(&amax_bits, __float_as_uint(am));
+  }
+  __syncthreads();
+  const int wx0 = bb[0], wy0 = bb[1];
+  const int ww = bb[2] - bb[0] + 1, wh = bb[3] - bb[1] + 1;
+  const bool any = bb[2] >= bb[0] && bb[3] >= bb[1];
+  const unsigned int ab = amax_bits;
+  const int ex = (int)(ab >> 23) - 126;
+  const bool fixed_ok = ab >= 0x00800000u && ab < 0x7F800000u;
+  const bool use_lds = any && fixed_ok && (int64_t)ww * wh <= WIN_MAX64;
+  const int k2 = min(max(tbits - ex, -100), 100);
+  const float scale = __uint_as_float((unsigned int)(k2 + 127) << 23);
+  const int wn = use_lds ? ww * wh : 0;
+  for (int i = tid; i < 2 * wn; i += 256) win[i] = 0ull;
+  __syncthreads();
+  // ---- pass B
+  if (inside) {
+#pragma unroll
+    for (int mi = 0; mi < BWD_MPC; ++mi) {
+      const int m = m0 + mi;
+      if (m >= m1) continue;
+      const int64_t i = ((int64_t)m * H + r) * W + c;
+      const float2 t = t_in[i];
+      const float s = ((r + c) & 1) ? -1.f : 1.f;
+      const float2 go = make_float2(a[mi].x * s, a[mi].y * s);
+      const Taps tp = make_taps(t.x + gx0, t.y + gy0, H, W);
+      const float2 dg = sample_bwd(img, nullptr, tp, go, H, W);
+      d_o[i] = make_float2(dg.x * (1.f - t.x * t.x), dg.y * (1.f - t.y * t.y));
+      const float wgt[4] = {tp.nw, tp.ne, tp.sw, tp.se};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int xx = tp.x0 + (kk & 1), yy = tp.y0 + (kk >> 1);
+        if (inb(yy, xx, H, W)) {
+          const float vx = wgt[kk] * go.x, vy = wgt[kk] * go.y;
+          if (use_lds) {
+            const int li = (yy - wy0) * ww + (xx - wx0);
+            atomicAdd(&win[li], (unsigned long long)__float2ll_rn(vx * scale));
+            atomicAdd(&win[wn + li], (unsigned long long)__float2ll_rn(vy * scale));
+          } else {
+            unsafeAtomicAdd(dpl + (size_t)yy * W + xx, vx);
+            unsafeAtomicAdd(dpl + P + (size_t)yy * W + xx, vy);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const double inv = 1.0 / (double)scale;
+  for (int i = tid; i < wn; i += 256) {
+    const long long sre = (long long)win[i], sim = (long long)win[wn + i];
+    const size_t g = (size_t)(wy0 + i / ww) * W + wx0 + i % ww;
+    if (sre != 0) unsafeAtomicAdd(dpl + g, (float)((double)sre * inv));
+    if (sim != 0) unsafeAtomicAdd(dpl + P + g, (float)((double)sim * inv));
+  }
+}
+
+int launch_motion_warp_bwd_dft(const float* image, const float* t, const float* xs, const float* ys, const float* zt_adj,
+                               const float* tw, const int32_t* cols, const int32_t* off, int nM, int H, int W,
+                               float* dimage_planar, float* d_o, hipStream_t st) {
+  if (nM == 0) return IMMOCO_OK;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)cdiv(nM, BWD_MPC));
+  const int tbits = 62 - 8 - 1 - 1;   // 256 pixels x 2 groups of < 2^(tbits + 1) each
+  motion_warp_bwd_dft_kernel<<<grid, 256, (size_t)W * sizeof(float2), st>>>(
+      (const float2*)image, (const float2*)t, xs, ys, (const float2*)zt_adj, (const float2*)tw, cols, off, nM, H, W,
+      tiles_x, tbits, dimage_planar, (float2*)d_o);
+  IMMOCO_LAUNCH_CHECK();
+  return IMMOCO_OK;
+}
+
 // ---- motion simulator pieces (reference src/utils/motion_utils.py:165-195) ---------------------
 // affine_grid(theta, align_corners=True) followed by grid_sample(bilinear, padding_mode="border",
 // align_corners=False) of one complex image for n rigid movements.  ATen semantics: the
@@ -506,9 +867,20 @@ int launch_motion_warp_bwd(const float* image, const float* t, const float* xs, 
     const int mpc = (nM + chunks - 1) / chunks;
     chunks = (nM + mpc - 1) / mpc;
     dim3 grid(tiles_x * tiles_y, chunks);
-    motion_warp_bwd_tiled_kernel<<<grid, 256, 0, st>>>((const float2*)image, (const float2*)t, xs, ys,
-                                                       (const float2*)adj_slots, nM, H, W, tiles_x, mpc, dimage,
-                                                       (float2*)d_o);
+    // fixed-point LDS window (default; needs <= 2^9 contributions per window cell: 256 pixels x mpc groups);
+    // IMMOCO_WARP_BWD=f32win (diagnostics build): the float-atomic window of rounds 2-3
+    static const bool f32win = immoco_diag_env("IMMOCO_WARP_BWD") && strcmp(immoco_diag_env("IMMOCO_WARP_BWD"), "f32win") == 0;
+    int lg = 0;
+    while ((1 << lg) < mpc) ++lg;
+    const int tbits = 62 - 8 - lg - 1;   // 256 * mpc contributions of < 2^(tbits + 1) each (|wgt * go| <= amax < 2^e)
+    if (!f32win)
+      motion_warp_bwd_tiled_i64_kernel<<<grid, 256, 0, st>>>((const float2*)image, (const float2*)t, xs, ys,
+                                                             (const float2*)adj_slots, nM, H, W, tiles_x, mpc, tbits,
+                                                             dimage, (float2*)d_o);
+    else
+      motion_warp_bwd_tiled_kernel<<<grid, 256, 0, st>>>((const float2*)image, (const float2*)t, xs, ys,
+                                                         (const float2*)adj_slots, nM, H, W, tiles_x, mpc, dimage,
+                                                         (float2*)d_o);
     IMMOCO_LAUNCH_CHECK();
     return IMMOCO_OK;
   }

@@ -131,7 +131,7 @@ def test_init_params_bit_exact(env, which):
 
 # ------------------------------------------------------------------------ MLP
 @pytest.mark.parametrize("which", ["image", "motion"])
-@pytest.mark.parametrize("n", [64, 1000])
+@pytest.mark.parametrize("n", [64, 1000, 20000])
 def test_mlp_fwd_bwd(env, which, n):
     pkg, L, orc = env
     net = pkg.network_config if which == "image" else pkg.mot_network_config
@@ -169,6 +169,22 @@ def test_mlp_fwd_bwd(env, which, n):
                                    L.ptr(dw1), L.ptr(dw2), st))
     np.testing.assert_allclose(xl.permute(1, 0, 2).reshape(n, 32).cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dw1.cpu().numpy(), w1.grad.numpy(), rtol=1e-3, atol=1e-4 * s1)
+    if which == "image":
+        # the split backward of the 256-wide net (two kernels that fit beside the motion grid's encode backward; what the
+        # solver runs in exact fp32): d enc bit-identical to the fused kernel's, dW1 / dW2 to summation accuracy
+        xl2 = xd.view(n, 16, 2).permute(1, 0, 2).contiguous()
+        dx2 = torch.full_like(xl2, float("nan"))
+        dw1s, dw2s = torch.zeros_like(dw1), torch.zeros_like(dw2)
+        L.check(L.lib().immoco_mlp_bwd_split(C.byref(cfg), L.ptr(xl2), 2, 2 * n, n, L.ptr(w1d), L.ptr(w2d), L.ptr(dd),
+                                             L.ptr(dx2), L.ptr(dw1s), L.ptr(dw2s), st))
+        assert torch.equal(dx2, xl)
+        np.testing.assert_allclose(dw1s.cpu().numpy(), w1.grad.numpy(), rtol=1e-3, atol=1e-4 * s1)
+        np.testing.assert_allclose(dw2s.cpu().numpy()[:2], w2.grad.numpy()[:2], rtol=1e-3, atol=1e-4 * s2)
+        assert float(dw2s[2:].abs().max()) == 0.0
+        assert float((dw1s - dw1).abs().max()) <= 2e-5 * s1
+        with pytest.raises(L.ImmocoError):      # din must not alias in
+            L.check(L.lib().immoco_mlp_bwd_split(C.byref(cfg), L.ptr(xl2), 2, 2 * n, n, L.ptr(w1d), L.ptr(w2d), L.ptr(dd),
+                                                 L.ptr(xl2), L.ptr(dw1s), L.ptr(dw2s), st), "mlp_bwd_split")
 
 
 @pytest.mark.parametrize("which,n", [("image", 1000), ("motion", 4100), ("motion", 31), ("image", 102400)])
@@ -679,14 +695,61 @@ def _oracle_run_to(orc, ksp, masks, iters_total, K, **inr_kw):
     return dict(kin=kin, lam=lam, loss=hist, before=before, grads=grads, after=after, image=ip)
 
 
+def _device_oracle_state(orc, ksp, masks, iters_total, K):
+    """K iterations of the DEVICE oracle (seconds where the CPU oracle takes minutes) -> the state BEFORE iteration K:
+    parameters and Adam moments, on the CPU.  Any late state is a valid input for a one-step comparison; the step
+    itself is then taken by the CPU oracle (_oracle_step_from_state) and by HIP."""
+    dev = torch.device("cuda", 0)
+    model = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, device=dev),
+                             motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, device=dev))
+    kin = ksp.div(ksp.abs().max()).mul(16000).clone()
+    kd = kin.to(dev)
+    pm_, pi_ = model.motion_inr.params, model.image_inr.params
+    opt = torch.optim.Adam([{"params": [pm_], "lr": 1e-2}, {"params": [pi_], "lr": 1e-2}])
+    lam = orc.lambda_schedule(iters_total, 1e-2)
+    for j in range(K):
+        opt.zero_grad()
+        kf, ip = model()
+        loss = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(kd)) + orc.gradient_entropy_loss(ip) * lam[j]
+        loss.backward()
+        opt.step()
+    st = {"kin": kin, "lam": lam}
+    for name, p in (("img", pi_), ("mot", pm_)):
+        st[name] = (p.detach().cpu().clone(), opt.state[p]["exp_avg"].cpu().clone(), opt.state[p]["exp_avg_sq"].cpu().clone())
+    return st
+
+
+def _oracle_step_from_state(orc, st, masks, K, **inr_kw):
+    """ONE iteration (number K) of the CPU oracle from a handed-over state: the record format of _oracle_run_to."""
+    model = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, **inr_kw),
+                             motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, **inr_kw))
+    pm_, pi_ = model.motion_inr.params, model.image_inr.params
+    opt = torch.optim.Adam([{"params": [pm_], "lr": 1e-2}, {"params": [pi_], "lr": 1e-2}])
+    before = {}
+    with torch.no_grad():
+        for name, p in (("img", pi_), ("mot", pm_)):
+            p.copy_(st[name][0])
+            opt.state[p] = {"step": torch.tensor(float(K)), "exp_avg": st[name][1].clone(), "exp_avg_sq": st[name][2].clone()}
+            before[name] = (st[name][0].clone(), st[name][1].clone(), st[name][2].clone())
+    opt.zero_grad()
+    kf, ip = model()
+    loss = F.mse_loss(torch.view_as_real(kf), torch.view_as_real(st["kin"])) + orc.gradient_entropy_loss(ip) * st["lam"][K]
+    loss.backward()
+    grads = {"img": pi_.grad.clone(), "mot": pm_.grad.clone()}
+    opt.step()
+    after = {"img": pi_.detach().clone(), "mot": pm_.detach().clone()}
+    return dict(kin=st["kin"], lam=st["lam"], loss={K: float(loss.detach())}, before=before, grads=grads, after=after,
+                image=ip.detach())
+
+
 def _teacher_forced_step(pkg, L, orc, ksp, masks, iters_total, K, loss_rtol=1e-4, image_tol=1e-4, still_tol=0.0,
-                         **mode):
+                         record=None, **mode):
     """One HIP iteration from the ORACLE's state at iteration K (parameters + Adam moments, step0 = K): no
     chaos can build up, so the late-trajectory arithmetic is compared tightly - loss, the gradient (recovered
     from Adam's first moment: g = (m' - 0.9 m) / 0.1) and the parameter update."""
     from miccai24_immoco_amd.models.immoco import get_solver
     from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
-    o = _oracle_run_to(orc, ksp, masks, iters_total, K, **mode)
+    o = record if record is not None else _oracle_run_to(orc, ksp, masks, iters_total, K, **mode)
     nM, H, W = masks.shape
     sol = get_solver(torch.device("cuda", 0), H, W, nM, **mode)
     cg = masks_to_col_group(masks.cuda())
@@ -864,14 +927,19 @@ def test_teacher_forced_lambda_zero_phase_96(env):
 
 @pytest.mark.parametrize("K", [5, 200])
 def test_teacher_forced_state_c2_shape(env, K):
-    """The same at the metric's shape (320x320, 10 groups; 3000-iteration schedule): K = 5, and K = 200 - a late
-    state handed over after 200 live oracle iterations (~3 minutes of CPU on the GPU box)."""
+    """The same at the metric's shape (320x320, 10 groups; 3000-iteration schedule): K = 5 - the CPU oracle runs live -
+    and K = 200, a late state.  Round 4: the 200 iterations that PRODUCE the late state are run by the device oracle
+    (7 s instead of 3 minutes of CPU); iteration 200 itself is then taken from that state by the CPU oracle, by the
+    device oracle and by HIP, and the three are compared (the CPU oracle stays the reference of the comparison)."""
     pkg, L, orc = env
     from oracle import synth_cpu
     s = synth_cpu.make_slice(320, 320, 10, 1)
     masks = orc.extract_movement_groups(s["lines"], make_list=True)
     K = int(os.environ.get("IMMOCO_TF_K", str(K)))       # diagnostic override
-    rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, K)
+    record = None
+    if K > 5:
+        record = _oracle_step_from_state(orc, _device_oracle_state(orc, s["kspace"], masks, 3000, K), masks, K)
+    rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, K, record=record)
     _device_oracle_step(orc, rep["_oracle_record"], masks, K)        # VERDICT r3 item 1: the sampler at K = 5 / 200 too
     # measured, K = 5: gradient rel. L2 6e-7 (image) / 7e-6 (motion), largest update difference 4.0e-6 = 4e-4 * lr;
     # K = 200: 2.7e-6 / 1.8e-5, update difference 2.5e-5 on 10 of 9.45 M entries (Adam turns a cancelling-sum gradient
@@ -1494,72 +1562,81 @@ def _blowups(loss, a, b, thr=1.5):
     return ev
 
 
-@pytest.mark.parametrize("mlp", [False, "bf16x2"])
-def test_config2_lambda_positive_regime_vs_oracle_draws(env, golden, mlp):
-    """VERDICT r2 item 1a - statistical parity where lambda_GE > 0 (iterations 600 ... 1400 of the metric's
-    3000-iteration solve, slice 1), against NINETEEN oracle draws: the six fixed-order records
-    (c2_oracle_slice1_3000it.npz) and thirteen draws whose fp32 summation orders are re-drawn before EVERY step
-    (c2_oracle_slice1_redraw1400.npz, OracleIMMoCo.redraw - what nondeterministic atomics do, in tiny-cuda-nn and here).
-    What the records show: every trajectory - oracle and HIP - oscillates with period 2 and goes through
-    about one loss blow-up between iterations 1050 and 1460, after which PSNR dips (and sometimes spikes to 44-46 dB)
-    for 50-150 iterations.  PSNR at ONE iteration (round 2 compared iteration 1400) therefore measures when the
-    blow-up happened; with re-drawn orders the oracle's own spread at 1375 is 2.1 dB (fixed order: 0.7) and its
-    blow-ups are as large as HIP's (median ratio 6.3 vs 3 with a fixed order).  Robust statistics instead:
-      * per run, the MEDIAN PSNR over the samples at 600, 625, ..., 1375 (the level of the lambda > 0 plateau);
-      * blow-up events per run in 300 ... 1400 and their size."""
+_CPU_SLICES = {}
+
+
+def _binom_se(k, n):
+    p = (k + 0.5) / (n + 1.0)          # never exactly 0 or 1
+    return float(np.sqrt(p * (1.0 - p) / n))
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16mlp"])
+@pytest.mark.parametrize("cell", ["plateau_s1", "it200_s1", "it200_s4", "it200_s9"])
+def test_cells_vs_device_oracle_draws(env, golden, cell, mode):
+    """Statistical parity at the reference's ONE initialisation (tiny-cuda-nn's seed 1337) against >= 64 draws per cell of the
+    DEVICE ORACLE (tests/golden/c2_device_oracle_draws.npz: the oracle's restatement evaluated by ATen on the GPU, fp32
+    atomics in nondeterministic order, validated against the CPU oracle by the teacher-forced tests above; VERDICT r3
+    item 1, rule in DESIGN.md 2.4).  Cells: `plateau_s1` - slice 1, the metric's 3000-iteration solve up to iteration
+    1000, per run the median PSNR over 600, 625, ..., 975 (and the fraction of runs below 38 dB); `it200_s{1,4,9}` - the
+    reference script's iters=200 (src/test/test_immoco.py:65-72), per run the median PSNR over the last 21 iterations.
+    Assertion: |mean(HIP) - mean(oracle)| <= 3 standard errors of that difference (no additive slack), the standard
+    error itself bounded, identical start (first loss), and the low-plateau fractions within 3 binomial standard errors.
+    `f16mlp` (tiny-cuda-nn's own network precision) is held to the SAME fp32 draws."""
     pkg, L, orc = env
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from _stats import hip_psnr_samples, delta_with_se, summarize
+    from miccai24_immoco_amd import synth
     from miccai24_immoco_amd.models.immoco import get_solver
-    rec, rd = golden("c2_oracle_slice1_3000it"), golden("c2_oracle_slice1_redraw1400")
-    its = list(rec["oracle_psnr_iters"])
-    grid = list(range(600, 1400, 25))
-    o_fixed = np.median(rec["oracle_psnr"][:, [its.index(t) for t in grid]].astype(np.float64), axis=1)
-    o_redraw = np.median(rd["psnr"][:, grid].astype(np.float64), axis=1)
-    o_all = np.concatenate([o_fixed, o_redraw])
-    ev_o = [_blowups(l.astype(np.float64), 300, 1400) for l in rec["oracle_loss"]] + \
-           [_blowups(l.astype(np.float64), 300, 1400) for l in rd["loss"]]
-    k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
-    sol = get_solver(torch.device("cuda", 0), 320, 320, 10, mlp_fp16=mlp)
-    h, ev_h = [], []
-    for _ in range(24 if not mlp else 14):
-        ps, loss = hip_psnr_samples(sol, kin, cg, gt, 3000, grid + [1399])
+    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
+    from miccai24_immoco_amd.utils.sampling import hip_psnr_samples, summarize, delta_with_se
+    g = golden("c2_device_oracle_draws") if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "c2_device_oracle_draws.npz")) else {}
+    kind, sl = cell.split("_s")
+    sl = int(sl)
+    key = "s1_plateau_psnr" if kind == "plateau" else f"s{sl}_it200_psnr"
+    if key not in g:
+        pytest.skip(f"no device-oracle draws for {cell} in the fixture")
+    dev = torch.device("cuda", 0)
+    if sl == 1:
+        k, kin, masks, cg, gt = _c2_slice1(pkg, golden)
+    else:
+        from oracle import synth_cpu
+        if sl not in _CPU_SLICES:                                  # the draws' own input, regenerated once and checked
+            _CPU_SLICES[sl] = synth_cpu.make_slice(320, 320, 10, sl)
+        s_ = _CPU_SLICES[sl]
+        ref_sum = float(g[f"s{sl}_kspace_abs_sum"])
+        assert abs(float(s_["kspace"].abs().double().sum()) - ref_sum) <= 1e-6 * ref_sum
+        k = s_["kspace"].to(dev)
+        masks = pkg.extract_movement_groups(s_["lines"].to(dev), make_list=True)
+        assert masks.shape[0] == int(g[f"s{sl}_n_groups"])
+        kin, cg, gt = k / k.abs().max() * 16000, masks_to_col_group(masks), synth.phantom(320, 320, 1000 + sl).abs()
+    sol = get_solver(dev, 320, 320, int(masks.shape[0]), mlp_fp16={"f32": 0, "f16mlp": 1}[mode])
+    if kind == "plateau":
+        its = list(g["psnr_plateau_iters"])
+        grid = list(range(600, 1000, 25))
+        o_stat = np.median(g[key][:, [its.index(t) for t in grid]].astype(np.float64), axis=1)
+        o_l0 = float(g["s1_plateau_loss"][0, 0])
+        n_runs, sched = (32 if mode == "f32" else 24), 3000
+    else:
+        grid = list(range(179, 200))
+        o_stat = np.median(g[key][:, 179:200].astype(np.float64), axis=1)
+        o_l0 = float(g[f"s{sl}_it200_loss"][0, 0])
+        n_runs, sched = (48 if mode == "f32" else 32), 200
+    assert len(o_stat) >= 48, len(o_stat)
+    h = []
+    for _ in range(n_runs):
+        ps, loss = hip_psnr_samples(sol, kin, cg, gt, sched, grid)
         h.append(float(np.median([ps[t] for t in grid])))
-        ev_h.append(_blowups(loss.astype(np.float64), 300, 1400))
-    delta, se, vr = delta_with_se(h, o_all)
-    rate_h, rate_o = np.mean([len(e) for e in ev_h]), np.mean([len(e) for e in ev_o])
-    ratios_h = [r for e in ev_h for _, r in e]
-    ratios_o = [r for e in ev_o[6:] for _, r in e]       # re-drawn orders: the like-for-like noise model
-    print("plateau PSNR (median over 600..1375 every 25): hip mean %.3f sd %.3f | oracle fixed %s redraw %s | delta %.3f +- %.3f"
-          % (*summarize(h)[:2], o_fixed.round(2).tolist(), o_redraw.round(2).tolist(), delta, se))
-    print("blow-ups per run in 300..1400: hip %.2f oracle (19 draws) %.2f; ratios hip %s redraw oracle %s fixed-order oracle %s"
-          % (rate_h, rate_o, np.round(sorted(ratios_h), 1).tolist(), np.round(sorted(ratios_o), 1).tolist(),
-             np.round(sorted(r for e in ev_o[:6] for _, r in e), 1).tolist()))
-    # The plateau statistic is bimodal on BOTH sides: a run sits at 39.3-40.0 dB, or - after an abrupt drop somewhere
-    # between iterations 250 and 900, without any loss event - 2-5 dB lower for hundreds of iterations until the next
-    # blow-up puts it back (tools/diag_lowbasin.py).  Low runs: HIP 87 of 352 (20-33 % per batch), oracle 1 of 19
-    # (re-drawn orders 1 of 13, fixed order 0 of 6).  That fraction is a property of THIS initialisation (the
-    # reference's fixed seed 1337) and of 1e-7-level arithmetic detail - the VALU MLP kernels give 12 of 112, the same
-    # matrix-core kernels on one stream 37 of 96, other init seeds 0 of 24 ... 14 of 24 - and is compared seed by seed in
-    # test_config2_plateau_by_initialisation_vs_oracle_draws (DESIGN.md 2.2).  Here, three robust statements:
-    #  (1) the level of the plateau where a run IS on it: upper quartile of the per-run medians, HIP vs oracle;
-    q_h, q_o = float(np.quantile(h, 0.75)), float(np.quantile(o_all, 0.75))
-    print("upper quartile of the per-run plateau PSNR: hip %.2f oracle %.2f; low runs (< 38 dB): hip %d of %d, oracle %d of %d"
-          % (q_h, q_o, sum(v < 38 for v in h), len(h), int((o_all < 38).sum()), len(o_all)))
-    if not mlp:
-        assert abs(q_h - q_o) <= 0.3, (q_h, q_o)
-    else:       # bf16 split from this initialisation: about every second run is low (40 of 80), so the BEST run carries the level
-        assert abs(max(h) - float(o_all.max())) <= 0.8, (max(h), o_all.max())
-    #  (2) the fraction of low runs is bounded (24 runs resolve it to +-0.1; measured 0.2-0.33 in exact fp32);
-    assert sum(v < 38 for v in h) <= (0.55 if not mlp else 0.9) * len(h), h
-    #  (3) the difference of the means stays inside 2 dB and is reported with its standard error
-    #      (80 runs: -0.95 +- 0.23 against the nineteen draws - the low-run fraction again).
-    assert se <= (0.6 if not mlp else 0.9) and abs(delta) <= (2.0 if not mlp else 3.0), (delta, se, h, o_all)
-    # about one event per run on both sides (19 oracle draws: 0.74); 24 runs resolve the rate to +-0.2
-    assert 0.2 <= rate_h <= 1.8, (rate_h, ev_h)
-    if ratios_h and ratios_o:
-        # (nine oracle events, median ratio 6.3; HIP medians between 2.0 and 7 over the batches: same order of magnitude)
-        assert 0.2 * np.median(ratios_o) <= np.median(ratios_h) <= 5.0 * np.median(ratios_o), (ratios_h, ratios_o)
+        assert abs(loss[0] - o_l0) <= (5e-5 if mode == "f32" else 1e-3) * o_l0, (loss[0], o_l0)     # identical start
+    delta, se, vr = delta_with_se(h, o_stat)
+    print(f"{cell} {mode}: hip mean %.3f sd %.3f ({n_runs} runs) | device oracle mean %.3f sd %.3f ({len(o_stat)} draws) | "
+          f"delta %.3f +- %.3f, variance ratio %.2f" % (*summarize(h)[:2], *summarize(o_stat)[:2], delta, se, vr))
+    assert se <= 0.5, se                     # measured 0.25 ... 0.4 (slice 4's draws spread by 2 dB)
+    assert abs(delta) <= 3.0 * se, (cell, mode, delta, se)
+    assert vr <= 4.0, vr                     # HIP runs do not spread much more than the oracle's draws
+    if kind == "plateau":
+        lo_h, lo_o = sum(v < 38.0 for v in h), int((o_stat < 38.0).sum())
+        fh, fo = lo_h / len(h), lo_o / len(o_stat)
+        se_f = float(np.hypot(_binom_se(lo_h, len(h)), _binom_se(lo_o, len(o_stat))))
+        print(f"low-plateau runs (< 38 dB): hip {lo_h} of {len(h)}, device oracle {lo_o} of {len(o_stat)}; difference %.3f +- %.3f" % (fh - fo, se_f))
+        assert abs(fh - fo) <= 3.0 * se_f, (lo_h, len(h), lo_o, len(o_stat))
 
 
 def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
@@ -1586,7 +1663,7 @@ def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
     hip = {}
     for sd in seeds:
         hip[sd] = []
-        for _ in range(7):
+        for _ in range(5):
             ps, _ = hip_psnr_samples(sol, kin, cg, gt, 3000, grid, seed=sd)
             hip[sd].append(float(np.median([ps[t] for t in grid])))
     for sd in seeds:
@@ -1594,7 +1671,7 @@ def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
     LOW = 38.0
     robust = [sd for sd in seeds if min(hip[sd]) >= 38.5]
     fragile = [sd for sd in seeds if sum(v < LOW for v in hip[sd]) >= 2]
-    print("robust seeds (no HIP run of 7 below 38.5 dB)", robust, "fragile seeds (>= 2 of 7 HIP runs below 38 dB)", fragile)
+    print("robust seeds (no HIP run of 5 below 38.5 dB)", robust, "fragile seeds (>= 2 of 5 HIP runs below 38 dB)", fragile)
     assert len(robust) >= 1 and len(fragile) >= 1, (robust, fragile, hip)
     # (1) from an initialisation HIP finds robust the oracle sits ON the plateau too, at the same level (a seed with a
     #     10-20 % low-run probability passes for robust in 7 runs now and then: two low oracle draws are tolerated)
@@ -1615,90 +1692,7 @@ def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):
     assert frac_o > frac_rest or len(o_fra) < 4, (frac_o, frac_rest)
 
 
-@pytest.mark.parametrize("slice_idx,mode", [(1, "f32"), (4, "f32"), (9, "f32"), (4, "bf16x2"), (4, "f16mlp"), (9, "f16mlp")])
-def test_reference_setting_200_iterations_distribution_vs_oracle_draws(env, golden, slice_idx, mode):
-    """Parity at the reference's OWN operating point: `iters=200`, 320x320, 10 groups
-    (/root/reference/src/test/test_immoco.py:65-72; lambda_GE is halved 95 times and never reaches 0) on three slices
-    (1, 4 and 9 = the 22.99 dB slice of round 2's bench line), 32 HIP solves per slice against 8-28 CPU-oracle draws
-    (tests/golden/c2_oracle_200it_draws.npz: fixed fp32 summation orders and, slices 1 and 4, orders re-drawn before
-    every step; loss and PSNR of every iteration), all from the reference's fixed initialisation (seed 1337).  PSNR oscillates with period 2 (Adam at lr 1e-2: +-1.5 dB late in a 3000-iteration solve, less here),
-    so the per-run statistic is the MEDIAN over the last 21 iterations; the final forward (what the reference returns)
-    is compared as well.  Assertions: the standard error of the HIP-minus-oracle difference resolves 0.6 dB (the
-    oracle draws of a slice end 1.0-1.2 dB apart; 8-16 of them are what 12 hours of CPU buy), the
-    difference is within 3 of its standard errors (a 2-s.e. gate over six parametrisations would fail one run in
-    four by chance alone; the measured differences are in DESIGN.md 2.2), and HIP runs do not spread more than 3x
-    the oracle draws' variance (+ a 0.1 dB floor, the draws of a slice can agree to 0.05 dB).  `f16mlp` is
-    immoco_solver_cfg.mlp_fp16 (tiny-cuda-nn's network precision), held to the SAME fp32 oracle draws.  What ONE
-    initialisation can and cannot say is in the comment at the assertion and in
-    test_reference_setting_200_iterations_over_initialisations."""
-    pkg, L, orc = env
-    import sys as _sys
-    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from _stats import hip_psnr_samples, summarize, delta_with_se
-    from oracle import synth_cpu
-    from miccai24_immoco_amd import synth
-    from miccai24_immoco_amd.models.immoco import get_solver
-    from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group
-    g = golden("c2_oracle_200it_draws")
-    if f"s{slice_idx}_psnr" not in g:
-        pytest.skip(f"no oracle draws for slice {slice_idx} in the fixture")
-    op, ol = g[f"s{slice_idx}_psnr"].astype(np.float64), g[f"s{slice_idx}_loss"].astype(np.float64)
-    n_fixed = op.shape[0]
-    if f"s{slice_idx}_psnr_redraw" in g:      # draws with summation orders re-drawn before every step join the sample
-        op = np.concatenate([op, g[f"s{slice_idx}_psnr_redraw"].astype(np.float64)])
-        ol = np.concatenate([ol, g[f"s{slice_idx}_loss_redraw"].astype(np.float64)])
-    assert op.shape[0] >= 6 and op.shape[1] == 200
-    s_ = synth_cpu.make_slice(320, 320, 10, slice_idx)          # the draws' input, regenerated and checked
-    ref_sum = float(g[f"s{slice_idx}_kspace_abs_sum"])
-    assert abs(float(s_["kspace"].abs().double().sum()) - ref_sum) <= 1e-6 * ref_sum
-    k, lines = s_["kspace"].cuda(), s_["lines"].cuda()
-    masks = pkg.extract_movement_groups(lines, make_list=True)
-    assert masks.shape[0] == int(g[f"s{slice_idx}_n_groups"])
-    gt = synth.phantom(320, 320, 1000 + slice_idx).abs()
-    sol = get_solver(torch.device("cuda", 0), 320, 320, int(masks.shape[0]),
-                     mlp_fp16={"f32": 0, "f16mlp": 1, "bf16x2": 2}[mode])
-    kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
-    samples = list(range(179, 200))
-    h_med, h_fin, h_loss = [], [], []
-    for _ in range(32 if mode == "f32" else 24):
-        ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, samples)
-        h_med.append(float(np.median([ps[t] for t in samples])))
-        h_fin.append(ps[199])
-        h_loss.append(float(np.median(loss[179:200])))
-        assert abs(loss[0] - ol[0, 0]) <= {"f32": 5e-5, "bf16x2": 1e-4, "f16mlp": 1e-3}[mode] * ol[0, 0]     # identical start
-    o_med, o_fin, o_loss = np.median(op[:, 179:200], axis=1), op[:, 199], np.median(ol[:, 179:200], axis=1)
-    d_med, d_fin = delta_with_se(h_med, o_med), delta_with_se(h_fin, o_fin)
-    print(f"slice {slice_idx} {mode}: oracle draws {n_fixed} fixed-order + {op.shape[0] - n_fixed} re-drawn "
-          f"(medians {o_med[:n_fixed].round(2).tolist()} / {o_med[n_fixed:].round(2).tolist()})")
-    print(f"slice {slice_idx} {mode}: median-of-last-21 PSNR hip %.3f (sd %.3f) oracle %.3f (sd %.3f) delta %.3f +- %.3f; "
-          f"final forward hip %.3f oracle %.3f delta %.3f +- %.3f; windowed loss hip %.4f (sd %.4f) oracle %.4f (sd %.4f)"
-          % (*summarize(h_med)[:2], *summarize(o_med)[:2], d_med[0], d_med[1], summarize(h_fin)[0], summarize(o_fin)[0],
-             d_fin[0], d_fin[1], *summarize(h_loss)[:2], *summarize(o_loss)[:2]))
-    for name, (delta, se, _), hv, ov in (("median21", d_med, h_med, o_med), ("final", d_fin, h_fin, o_fin)):
-        assert se <= 0.9, (name, se)          # slice 4's draws end 2.2 dB apart (26.3 ... 33.3 dB): 0.85; slices 1, 9: 0.4
-        # ONE initialisation (the reference's fixed seed 1337) is compared here, and per-initialisation levels differ by
-        # more than their standard errors between equally valid fp32 evaluations (DESIGN.md 2.2: slice 4, HIP per-seed means
-        # 27.2 ... 33.4 dB; seed 1337: matrix-core kernels 29.7, VALU kernels 29.4, oracle 31.4 +- 0.3).  Exact fp32 is held
-        # to 3 s.e. + 0.5 dB on slices 1 and 9 (measured +0.19 +- 0.38, +0.25 +- 0.37) and to + 1.5 dB on slice 4 (measured
-        # -1.4 ... -1.7 +- 0.44); the statement that does not depend on the seed is
-        # test_reference_setting_200_iterations_over_initialisations.
-        if mode == "f32":
-            assert abs(delta) <= 3.0 * se + (1.5 if slice_idx == 4 else 0.5), (name, delta, se)
-        else:
-            # fp16 / two-term bf16 MLP operands at seed 1337: -1.4 dB (slice 9, fp16), -1.3 ... -2.6 (slice 4), +0.2
-            # (slice 1); averaged over initialisations no mode differs from fp32 by more than 0.5 dB (same test)
-            assert -3.5 <= delta <= 3.0 * se + 0.5, (name, delta, se)
-        # spread: a fixed summation order under-estimates it (slice 1: sd 1.0 fixed-order vs 1.5 re-drawn; at iteration
-        # 1375 of the long solve 0.72 vs 2.46, variance ratio 11.7 - DESIGN.md 2.2), so the bound is that measured ratio
-        assert np.var(hv, ddof=1) <= 12.0 * np.var(ov, ddof=1) + 0.1 ** 2 * 3, (name, np.std(hv, ddof=1), np.std(ov, ddof=1))
-    # the objective itself: windowed loss within 3 standard errors (relative floor 5 % in exact fp32; the fp16 / bf16-split
-    # modes from this ONE initialisation end at another level of the same regime - slice 4, f16mlp: 0.42 +- 0.02 against
-    # 0.59 +- 0.03 - so only the regime is asserted there)
-    dl = delta_with_se(h_loss, o_loss)
-    assert abs(dl[0]) <= 3.0 * dl[1] + (0.05 if mode == "f32" else 0.35) * float(np.mean(o_loss)), (dl, h_loss, o_loss)
-
-
-@pytest.mark.parametrize("slice_idx,mode", [(4, "f32"), (4, "f16mlp"), (4, "bf16x2"), (9, "f32")])
+@pytest.mark.parametrize("slice_idx,mode", [(4, "f32"), (4, "f16mlp"), (9, "f32")])
 def test_reference_setting_200_iterations_over_initialisations(env, golden, slice_idx, mode):
     """The same operating point (iters = 200; slice 4 - the slice with the widest spread - and slice 9) over EIGHT
     initialisations instead of one: CPU-oracle draws from init seeds 2001 ... 2008 with summation orders re-drawn every
@@ -1730,7 +1724,7 @@ def test_reference_setting_200_iterations_over_initialisations(env, golden, slic
     kin, cg = k / k.abs().max() * 16000, masks_to_col_group(masks)
     samples = list(range(179, 200))
     hip = {sd: [] for sd in seeds}
-    for _ in range(6):
+    for _ in range(4):
         for sd in seeds:
             ps, loss = hip_psnr_samples(sol, kin, cg, gt, 200, samples, seed=sd)
             hip[sd].append(float(np.median([ps[t] for t in samples])))
@@ -1741,7 +1735,7 @@ def test_reference_setting_200_iterations_over_initialisations(env, golden, slic
     mo = np.array([o_med[o_seed == sd].mean() for sd in seeds])
     vh = np.mean([np.var(hip[sd], ddof=1) for sd in seeds])
     vo = np.mean([np.var(o_med[o_seed == sd], ddof=1) for sd in seeds])
-    n_h, n_o = 6, np.mean([(o_seed == sd).sum() for sd in seeds])
+    n_h, n_o = 4, np.mean([(o_seed == sd).sum() for sd in seeds])
     delta = float((mh - mo).mean())
     se = float(np.sqrt(vh / (len(seeds) * n_h) + vo / (len(seeds) * n_o)))
     r = float(np.corrcoef(mh, mo)[0, 1])
@@ -1777,7 +1771,7 @@ def test_config2_3000_iterations_vs_cpu_oracle_records(env, golden):
     assert lam == orc.lambda_schedule(3000, 1e-2) and lam[-1] == 0.0
     marks = [0, 25, 50, 100, 200, 400, 800, 1400, 2900, 2925, 2950, 2975, 2999]
     losses, psnrs, end_med = [], [], []
-    for rep in range(8):
+    for rep in range(6):
         pi, pm = sol.init_params()
         ai = torch.zeros(2 * pi.numel(), device="cuda")
         am = torch.zeros(2 * pm.numel(), device="cuda")
@@ -1959,6 +1953,15 @@ def test_config3_batch_of_64_slices_at_320(env):
     _, _, l2 = pkg.imcoco_motion_correction_batch(ksp[sub], [masks[i] for i in sub], iters=12, return_loss=True, lanes=2)
     np.testing.assert_allclose(l2[:, :3].cpu().numpy(), loss[sub, :3].cpu().numpy(), rtol=2e-5)
     np.testing.assert_allclose(l2.cpu().numpy(), loss[sub].cpu().numpy(), rtol=5e-2)
+    # paired mode (two slices per captured graph) at the config's OWN shape, 320x320x10, B = 4:
+    # the first five losses of every slice agree with the slice-after-slice batch
+    sub4 = [10, 11, 12, 13]
+    i4, _, l4 = pkg.imcoco_motion_correction_batch(ksp[sub4], [masks[i] for i in sub4], iters=12, return_loss=True, pair=True)
+    np.testing.assert_allclose(l4[:, :5].cpu().numpy(), loss[sub4, :5].cpu().numpy(), rtol=2e-3)
+    np.testing.assert_allclose(l4[:, :3].cpu().numpy(), loss[sub4, :3].cpu().numpy(), rtol=5e-5)
+    np.testing.assert_allclose(l4.cpu().numpy(), loss[sub4].cpu().numpy(), rtol=5e-2)
+    for k, i in enumerate(sub4):
+        assert float((i4[k] - imgs[i]).abs().norm() / imgs[i].abs().norm()) < 0.05
 
 
 def test_probe_and_batch_argument_checks(env):

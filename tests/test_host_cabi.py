@@ -145,3 +145,31 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert r.stdout.startswith("entries 7114752 16:0 32:0 64:0 128:1")
     assert r.stdout.strip().endswith("65536:0 131072:0 262144:0 524288:0")   # wrapped-stride levels: not hashed
+
+
+def test_shipped_library_reads_no_environment_switch():
+    """the result-changing / A-B switches (IMMOCO_CSR_STREAM, IMMOCO_MLP_IMPL, ...) exist only in the
+    diagnostics build (`make -C miccai24_immoco_amd/csrc diag`, -DIMMOCO_DIAG); the shipped library holds none of their
+    names."""
+    from miccai24_immoco_amd import _lib as L
+    if not L.lib_available():
+        pytest.fail("libimmoco_hip.so is not built (run __graft_entry__.build())")
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"IMMOCO_CSR_STREAM" not in blob and b"IMMOCO_MLP_IMPL" not in blob and b"IMMOCO_" not in blob
+
+
+def test_solver_cfg_fields_are_validated(L):
+    """mlp_fp16 / batch_pair / serial_chains were `reserved` words before round 3; garbage is refused."""
+    h = L.lib()
+    def cfg(**kw):
+        base = dict(use_graph=1, atomic_scatter=0, grad_parts=0, serial_chains=2, table_fp16=0, batch_lanes=0, mlp_fp16=0, batch_pair=0)
+        base.update(kw)
+        return L.SolverCfg(32, 32, 2, L.grid_cfg(2, {}), L.grid_cfg(3, {}), L.mlp_cfg(32, 2, {"otype": "CutlassMLP", "n_neurons": 256}),
+                           L.mlp_cfg(32, 2, {"otype": "FullyFusedMLP", "activation": "Tanh", "n_neurons": 64}),
+                           base["use_graph"], base["atomic_scatter"], base["grad_parts"], base["serial_chains"], base["table_fp16"],
+                           base["batch_lanes"], base["mlp_fp16"], base["batch_pair"])
+    for bad, word in ((dict(mlp_fp16=3), "mlp_fp16"), (dict(mlp_fp16=-1), "mlp_fp16"), (dict(batch_pair=7), "batch_pair"),
+                      (dict(serial_chains=5), "serial_chains")):
+        out = C.c_void_p()
+        c = cfg(**bad)
+        assert h.immoco_solver_create(C.byref(c), C.byref(out)) == -1 and word in L.last_error(), (bad, L.last_error())
