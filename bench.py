@@ -310,42 +310,61 @@ def main():
         psnr_in = [crop_psnr(IFFT(tsl[j]["kspace"]).abs().cpu(), tsl[j]["gt"].abs().cpu()) for j in range(K * B)]
         psnr_delta = None
         if ref_rec is not None and K >= 1:
-            # HIP run-to-run spread of the same slice (outside the timed region).  The trajectory is chaotic: every run
-            # - HIP and oracle alike - goes through about one loss blow-up between iterations 1050 and 1460 and recovers
-            # within ~150 iterations (tools/diag_blowups.py), and PSNR oscillates with period 2 by +-1.5 dB, so single-run,
-            # single-iteration PSNR says little: seven extra runs are sampled at 1350 ... 1450 (every 25 iterations, the
-            # oracle records' grid; median per run = the lambda_GE > 0 checkpoint) and at the end, with standard errors.
+            # PSNR against the reference side (outside the timed region).  The trajectory is chaotic (PSNR oscillates with
+            # period 2 by +-1.5 dB, every run goes through a loss blow-up between iterations 1050 and 1460), so only
+            # distributions compare: per run the MEDIAN PSNR over a window of iterations, HIP mean minus oracle mean with
+            # the standard error of that difference.  Two references, both data fixtures (no oracle code runs here):
+            #  * plateau (lambda_GE > 0): iterations 600, 625, ..., 975 against >= 64 draws of the DEVICE oracle (ATen on the
+            #    GPU, fp32 atomics; tests/golden/c2_device_oracle_draws.npz, tools/device_oracle_sampler.py): 24 HIP runs;
+            #  * end of the solve (2900 ... 2999) against the six full CPU-oracle records: 6 HIP runs.
             from miccai24_immoco_amd.utils.sampling import hip_psnr_samples, summarize, delta_with_se
+            from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group as _m2c
             import numpy as np
             rec = np.load(os.path.join(fx, "c2_oracle_slice1_3000it.npz"))
             its = list(rec["oracle_psnr_iters"])
-            mid_it, end_it = [1350, 1375, 1400, 1425, 1450], [2900, 2925, 2950, 2975, 2999]
-            o_mid = np.median(rec["oracle_psnr"][:, [its.index(t) for t in mid_it]], axis=1)
+            end_it, pl_it = [2900, 2925, 2950, 2975, 2999], list(range(600, 1000, 25))
             o_end = np.median(rec["oracle_psnr"][:, [its.index(t) for t in end_it]], axis=1)
             o_last = rec["oracle_psnr"][:, -1]
             ksl = tsl[0]["kspace"]
-            kin1 = ksl / ksl.abs().max() * 16000
-            from miccai24_immoco_amd.utils.motion_utils import masks_to_col_group as _m2c
-            h_mid, h_end, h_last = [], [], [psnr[0]]
-            for _ in range(7):
-                ps_, _l = hip_psnr_samples(the_solver(), kin1, _m2c(tsl[0]["masks"]), tsl[0]["gt"].abs().cpu(), 3000, mid_it + end_it)
-                h_mid.append(float(np.median([ps_[t] for t in mid_it])))
+            kin1, cg1, gt1 = ksl / ksl.abs().max() * 16000, _m2c(tsl[0]["masks"]), tsl[0]["gt"].abs().cpu()
+            h_end, h_last, h_pl = [], [psnr[0]], []
+            for _ in range(6):
+                ps_, _l = hip_psnr_samples(the_solver(), kin1, cg1, gt1, 3000, pl_it + end_it)
+                h_pl.append(float(np.median([ps_[t] for t in pl_it])))
                 h_end.append(float(np.median([ps_[t] for t in end_it])))
                 h_last.append(ps_[2999])
-            d_mid, d_end, d_last = delta_with_se(h_mid, o_mid), delta_with_se(h_end, o_end), delta_with_se(h_last, o_last)
-            psnr_delta = {"psnr_delta_db": round(d_last[0], 3), "psnr_delta_se_db": round(d_last[1], 3),
-                          "slice": "config C2, slice 1", "n_hip_runs": len(h_last), "n_oracle_records": int(len(o_last)),
-                          "hip_psnr_db": [round(p, 3) for p in h_last], "hip_timed_run_psnr_db": round(psnr[0], 3),
-                          "oracle_psnr_db": ref_rec["oracle_psnr_db"], "oracle_source": ref_rec["source"],
-                          "at_1400_window_median": {"delta_db": round(d_mid[0], 3), "se_db": round(d_mid[1], 3),
-                                                    "variance_ratio": round(d_mid[2], 2), "n_hip_runs": len(h_mid),
-                                                    "hip_db": [round(v, 2) for v in h_mid], "oracle_db": [round(float(v), 2) for v in o_mid],
-                                                    "what": "per run: median PSNR over iterations 1350, 1375, 1400, 1425, 1450 "
-                                                            "(lambda_GE = 1e-2 still)"},
+            plateau = None
+            dpath = os.path.join(fx, "c2_device_oracle_draws.npz")
+            if os.path.exists(dpath):
+                dd = np.load(dpath)
+                if "s1_plateau_psnr" in dd:
+                    pits = list(dd["psnr_plateau_iters"])
+                    o_pl = np.median(dd["s1_plateau_psnr"][:, [pits.index(t) for t in pl_it]].astype(np.float64), axis=1)
+                    for _ in range(18):
+                        ps_, _l = hip_psnr_samples(the_solver(), kin1, cg1, gt1, 3000, pl_it)
+                        h_pl.append(float(np.median([ps_[t] for t in pl_it])))
+                    d_pl = delta_with_se(h_pl, o_pl)
+                    plateau = {"delta_db": round(d_pl[0], 3), "se_db": round(d_pl[1], 3), "variance_ratio": round(d_pl[2], 2),
+                               "n_hip_runs": len(h_pl), "n_oracle_draws": int(len(o_pl)),
+                               "hip_mean_db": round(float(np.mean(h_pl)), 3), "oracle_mean_db": round(float(o_pl.mean()), 3),
+                               "low_runs_below_38db": {"hip": int(sum(v < 38 for v in h_pl)), "oracle": int((o_pl < 38).sum())},
+                               "what": "per run: median PSNR over iterations 600, 625, ..., 975 (lambda_GE = 1e-2); oracle = "
+                                       "device-oracle draws (fp32, ATen atomics) of tests/golden/c2_device_oracle_draws.npz"}
+            d_end, d_last = delta_with_se(h_end, o_end), delta_with_se(h_last, o_last)
+            psnr_delta = {"psnr_delta_db": plateau["delta_db"] if plateau else round(d_end[0], 3),
+                          "psnr_delta_se_db": plateau["se_db"] if plateau else round(d_end[1], 3),
+                          "psnr_delta_is": "plateau_600_975 (device-oracle draws)" if plateau else "end_window_median (CPU records)",
+                          "slice": "config C2, slice 1", "plateau_600_975": plateau,
                           "end_window_median": {"delta_db": round(d_end[0], 3), "se_db": round(d_end[1], 3),
-                                                "variance_ratio": round(d_end[2], 2), "n_hip_runs": len(h_end)},
-                          "note": "HIP mean minus oracle-record mean with the standard error of that difference; 8 runs resolve "
-                                  "~0.5 dB, the suite's 32-run distribution tests (tests/test_gpu_ops.py) and DESIGN.md 2.2 resolve more"}
+                                                "variance_ratio": round(d_end[2], 2), "n_hip_runs": len(h_end),
+                                                "n_oracle_records": int(len(o_end)),
+                                                "what": "per run: median PSNR over 2900, 2925, ..., 2999 (lambda_GE = 0) against the six "
+                                                        "full CPU-oracle records (tests/golden/c2_oracle_slice1_3000it.npz)"},
+                          "final_forward": {"delta_db": round(d_last[0], 3), "se_db": round(d_last[1], 3), "n_hip_runs": len(h_last),
+                                            "hip_timed_run_psnr_db": round(psnr[0], 3)},
+                          "reference_script_iters_200": "profiles/r04_cells_vs_device_oracle.txt: slices 1 / 4 / 9, 64 HIP runs against "
+                                                        "64 device-oracle draws each (the suite's test_cells_vs_device_oracle_draws re-measures them)",
+                          "note": "HIP mean minus oracle mean with the standard error of that difference (both samples)"}
         # ---- roofline: per-kernel device time with HIP events on the solver's stream ----------
         solver = the_solver()
         sl = slices[0]
@@ -383,10 +402,12 @@ def main():
         b_iter = (30 if args.table_fp16 else 28) * (solver.n_params_image + solver.n_params_motion) + 8 * H * W
         iter_ms_graph = ms_per_step / args.iters / B
         traffic, traffic_src = None, None
-        tname = "r03_traffic" + ("_c5" if args.workload == "c5" else "") + \
-            ({0: "", 1: "_f16mlp", 2: "_bf16x2"}[int(args.mlp_fp16)]) + ".json"
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath):
+        tsuffix = ("_c5" if args.workload == "c5" else "") + ({0: "", 1: "_f16mlp", 2: "_bf16x2"}[int(args.mlp_fp16)]) + ".json"
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_traffic" + tsuffix) for r in ("r04", "r03"))
+                      if os.path.exists(q)), None)
+        if tpath is None:
+            traffic_src = "no stored --pmc traffic file for this mode (profiles/r0N_traffic" + tsuffix + ")"
+        if tpath is not None:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj["kernels"][name]["hbm_bytes_corrected"]

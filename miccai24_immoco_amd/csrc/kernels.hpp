@@ -42,9 +42,11 @@ int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
 // split backward of the 256-wide net (mlp_mfma.hip): d enc (out of place) and dW1 / dW2 as two kernels that fit beside
 // the motion grid's encode backward
 int launch_mlp_bwd_denc(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
-                        const float* w2, const float* dout, float* din, hipStream_t st, int64_t dout_plane = 0);
+                        const float* w2, const float* dout, float* din, hipStream_t st, int64_t dout_plane = 0,
+                        const float* dout2 = nullptr);   // dout2: a second planar addend of dout (same layout)
 int launch_mlp_bwd_dw(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
-                      const float* w2, const float* dout, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane = 0);
+                      const float* w2, const float* dout, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane = 0,
+                      const float* dout2 = nullptr);
 
 // mlp_f16.hip — tiny-cuda-nn's operand precision: fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16);
 // the backward scales dout by `scale` (tcnn's loss scale, 128) before rounding it to fp16
@@ -60,7 +62,8 @@ int launch_mlp_bwd_f16(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, i
 // grid's encode backward
 int launch_mlp_bwd_f16_split(const immoco_mlp_cfg& cfg, int part, const float* in, int64_t ps, int64_t ls, int64_t n,
                              const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                             hipStream_t st, int64_t dout_plane, float scale, bool enc_half = false);
+                             hipStream_t st, int64_t dout_plane, float scale, bool enc_half = false,
+                             const float* dout2 = nullptr);
 
 // mlp_bf16x2.hip - (nearly) fp32 accuracy on the 16-bit matrix cores: every operand split into two bf16 terms, three
 // MFMAs per product, fp32 everywhere else (relative product error <= 2^-16.5)

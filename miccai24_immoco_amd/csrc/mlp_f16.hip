@@ -101,6 +101,16 @@ __device__ __forceinline__ void build_w1_frags(const float* __restrict__ w1, h8v
     }
   }
 }
+// the AW fragments of `njl` hidden tiles starting at tile jt0 only (split backward, MODE 2): aw_local[jl][s][lane]
+__device__ __forceinline__ void build_w1_frags_range(const float* __restrict__ w1, h8v* aw_local, int jt0, int njl, int tid) {
+  for (int c = tid; c < njl * 32 * 4; c += 256) {
+    const int jloc = c >> 2, q = c & 3, s = q >> 1, h = q & 1, jl = jloc >> 5, rho = jloc & 31;
+    const int cg = (jt0 * 32 + jloc) * 4 + q;   // index of the 8-float chunk in W1
+    const float4 a = reinterpret_cast<const float4*>(w1)[cg * 2], b = reinterpret_cast<const float4*>(w1)[cg * 2 + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    aw_local[(jl * 2 + s) * 64 + h * 32 + rho] = pk8(v);
+  }
+}
 //   AW2[jt][s][lane]  elem i = W2[o = r][jt*32 + 16s + 8(i>>2) + 4h + (i&3)] for r < 2, else 0   (A of out^T)
 template <int HID>
 __device__ __forceinline__ void build_w2_frags(const float* __restrict__ w2, h8v* aw2, int tid) {
@@ -215,15 +225,17 @@ template <int HID, int ACT, bool EH, int MODE = 0>
 __global__ __launch_bounds__(256, MODE == 0 ? (HID == 64 ? 2 : 1) : 3) void mlp_bwd_f16_kernel(
     const float* in /* may alias din (MODE 0) */, int64_t ps, int64_t ls, int64_t n, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ dout, float* din, float* __restrict__ dw1,
-    float* __restrict__ dw2, int64_t n_tiles, int64_t dout_plane, float scale) {
+    float* __restrict__ dw2, int64_t n_tiles, int64_t dout_plane, float scale, const float* __restrict__ dout2 = nullptr) {
   constexpr int NJT = HID / 32;
   constexpr int NJL = MODE == 2 ? F16_NJW : NJT;                   // hidden tiles this workgroup works on
   constexpr int UNR = MODE == 1 ? 2 : NJL;                         // unroll factor of the loop over them
   const int jt0 = MODE == 2 ? (int)blockIdx.y * F16_NJW : 0;       // first of them
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  h8v* aw = reinterpret_cast<h8v*>(smem);                          // [NJT][2][64]
-  h8v* awt = aw + NJT * 2 * 64;                                    // [NJT][2][64]
-  float* w2s = reinterpret_cast<float*>(awt + NJT * 2 * 64);       // [2][HID], fp16-rounded values
+  // MODE 2 keeps only its own hidden tiles' W1 fragments and no W1^T fragments (34 KB instead of 62: the kernel has to
+  // fit beside the encode backward's workgroups)
+  h8v* aw = reinterpret_cast<h8v*>(smem);                          // [NJT][2][64]   (MODE 2: [NJL][2][64], local tile index)
+  h8v* awt = aw + (MODE == 2 ? NJL : NJT) * 2 * 64;                // [NJT][2][64]   (MODE 2: none)
+  float* w2s = reinterpret_cast<float*>(awt + (MODE == 2 ? 0 : NJT) * 2 * 64);   // [2][HID], fp16-rounded values
   unsigned char* wv_all = reinterpret_cast<unsigned char*>(w2s + 2 * HID);
   constexpr int WAVE_BYTES = 3 * IMG_BYTES + 128;                  // three images + the dout tile [2][32] fp16
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,7 +245,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? (HID == 64 ? 2 : 1) : 3) void mlp_
   unsigned char* img_d = wv + IMG_BYTES;       // dpre tile  [point][hidden of the current jt]
   unsigned char* img_h = wv + 2 * IMG_BYTES;   // h tile     [point][hidden of the current jt]
   _Float16* dm = reinterpret_cast<_Float16*>(wv + 3 * IMG_BYTES);  // [2][32]
-  build_w1_frags<HID>(w1, aw, MODE == 2 ? nullptr : awt, threadIdx.x);
+  if (MODE == 2) build_w1_frags_range(w1, aw, jt0, NJL, threadIdx.x);
+  else build_w1_frags<HID>(w1, aw, awt, threadIdx.x);
   for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = rh(w2[i]);
   __syncthreads();
 
@@ -263,8 +276,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? (HID == 64 ? 2 : 1) : 3) void mlp_
     const int64_t qc = q < n ? q : n - 1;
     const float mq = q < n ? 1.f : 0.f;
     load_enc_raw<EH>(in, ps, ls, q, n, h, nx);
-    if (dout_plane) {  // wave-uniform
-      nx_d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
+    if (dout_plane) {  // wave-uniform; dout2: a second planar addend (the warp backward's share of dL/dimage)
+      nx_d = make_float2(dout[qc], dout[dout_plane + qc]);
+      if (MODE != 0 && dout2) nx_d = make_float2(dout2[qc] + nx_d.x, dout2[dout_plane + qc] + nx_d.y);
+      nx_d = make_float2(nx_d.x * mq, nx_d.y * mq);
     } else {
       const float2 dv = *reinterpret_cast<const float2*>(dout + qc * 2);
       nx_d = make_float2(dv.x * mq, dv.y * mq);
@@ -311,8 +326,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? (HID == 64 ? 2 : 1) : 3) void mlp_
       const int jt = jt0 + jl;
       // ---- L1: rows = hidden, col = point
       f32x16 pre = {0.f};
-      pre = mfma16(aw[(jt * 2) * 64 + lane], eb[0], pre);
-      pre = mfma16(aw[(jt * 2 + 1) * 64 + lane], eb[1], pre);
+      const int ja = MODE == 2 ? jl : jt;   // index of the tile's fragments in LDS
+      pre = mfma16(aw[(ja * 2) * 64 + lane], eb[0], pre);
+      pre = mfma16(aw[(ja * 2 + 1) * 64 + lane], eb[1], pre);
       h2v hp[8], dp[8];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -472,11 +488,12 @@ static int launch_bwd_f16_t(const float* in, int64_t ps, int64_t ls, int64_t n, 
 template <int ACT, bool EH, int MODE>
 static int launch_bwd_f16_split_t(const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1, const float* w2,
                                   const float* dout, float* din, float* dw1, float* dw2, hipStream_t st,
-                                  int64_t dout_plane, float scale) {
+                                  int64_t dout_plane, float scale, const float* dout2) {
   constexpr int HID = 256, NJT = HID / 32;
   const int64_t n_tiles = cdiv(n, 32);
-  // MODE 1: W1 and W1^T fragments + W2; MODE 2: the same layout (only the W1 fragments are built) + the per-wave images
-  const size_t sm = MODE == 1 ? (size_t)NJT * 2 * 64 * 16 * 2 + (size_t)2 * HID * 4 : f16_bwd_smem(HID);
+  // MODE 1: W1 and W1^T fragments + W2 (34 KB); MODE 2: its own tiles' W1 fragments + W2 + the per-wave images (34 KB)
+  const size_t sm = MODE == 1 ? (size_t)NJT * 2 * 64 * 16 * 2 + (size_t)2 * HID * 4
+                              : (size_t)F16_NJW * 2 * 64 * 16 + (size_t)2 * HID * 4 + (size_t)4 * (3 * IMG_BYTES + 128);
   static bool attr_set = false;
   if (!attr_set) {
     IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_f16_kernel<HID, ACT, EH, MODE>),
@@ -485,21 +502,22 @@ static int launch_bwd_f16_split_t(const float* in, int64_t ps, int64_t ls, int64
   }
   const dim3 grid((unsigned)std::min<int64_t>(cdiv(n_tiles, 4), MODE == 1 ? 512 : 256), MODE == 2 ? NJT / F16_NJW : 1);
   mlp_bwd_f16_kernel<HID, ACT, EH, MODE><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles,
-                                                                dout_plane, scale);
+                                                                dout_plane, scale, dout2);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
 
 int launch_mlp_bwd_f16_split(const immoco_mlp_cfg& cfg, int part, const float* in, int64_t ps, int64_t ls, int64_t n,
                              const float* w1, const float* w2, const float* dout, float* din, float* dw1, float* dw2,
-                             hipStream_t st, int64_t dout_plane, float scale, bool enc_half) {
+                             hipStream_t st, int64_t dout_plane, float scale, bool enc_half, const float* dout2) {
   if (n == 0) return IMMOCO_OK;
+  IMMOCO_REQUIRE(dout2 == nullptr || dout_plane != 0, "mlp_bwd_f16_split: a second dout addend needs the planar layout");
   IMMOCO_REQUIRE(cfg.n_hidden == 256 && (part == 1 || part == 2), "mlp_bwd_f16_split: 256-wide net, part 1 or 2");
   IMMOCO_REQUIRE(part == 2 || in != din, "mlp_bwd_f16_split: din must not alias in");
   IMMOCO_REQUIRE(enc_half || ((ps % 2) == 0 && (ls % 2) == 0), "mlp input strides must be even");
 #define IMMOCO_SPLIT(A, M)                                                                                                 \
-  return enc_half ? launch_bwd_f16_split_t<A, true, M>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale)  \
-                  : launch_bwd_f16_split_t<A, false, M>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale)
+  return enc_half ? launch_bwd_f16_split_t<A, true, M>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale, dout2)  \
+                  : launch_bwd_f16_split_t<A, false, M>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane, scale, dout2)
   if (cfg.activation == IMMOCO_ACT_TANH) {
     if (part == 1) IMMOCO_SPLIT(IMMOCO_ACT_TANH, 1);
     IMMOCO_SPLIT(IMMOCO_ACT_TANH, 2);

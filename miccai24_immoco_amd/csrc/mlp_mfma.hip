@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, 4) void mlp_bwd_denc_kernel(const float* __res
                                                               int64_t n, const float* __restrict__ w1,
                                                               const float* __restrict__ w2,
                                                               const float* __restrict__ dout, float* __restrict__ din,
-                                                              int64_t n_tiles, int64_t dout_plane) {
+                                                              int64_t n_tiles, int64_t dout_plane,
+                                                              const float* __restrict__ dout2) {
   constexpr int NJT = HID / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* aw = reinterpret_cast<float4*>(smem);                  // W1 fragments    [NJT][4][64]
@@ -435,8 +436,10 @@ __global__ __launch_bounds__(256, 4) void mlp_bwd_denc_kernel(const float* __res
     float eb[16];
     load_enc_b(in, ps, ls, p, n, h, eb);
     float2 d;
-    if (dout_plane) {  // wave-uniform
-      d = make_float2(dout[pc] * mq, dout[dout_plane + pc] * mq);
+    if (dout_plane) {  // wave-uniform; dout2: a second planar addend (the warp backward's share of dL/dimage)
+      d = make_float2(dout[pc], dout[dout_plane + pc]);
+      if (dout2) d = make_float2(dout2[pc] + d.x, dout2[dout_plane + pc] + d.y);
+      d = make_float2(d.x * mq, d.y * mq);
     } else {
       const float2 dv = *reinterpret_cast<const float2*>(dout + pc * 2);
       d = make_float2(dv.x * mq, dv.y * mq);
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256, 4) void mlp_bwd_dw_kernel(const float* __restr
                                                             const float* __restrict__ w2,
                                                             const float* __restrict__ dout, float* __restrict__ dw1,
                                                             float* __restrict__ dw2, int64_t n_tiles,
-                                                            int64_t dout_plane) {
+                                                            int64_t dout_plane, const float* __restrict__ dout2) {
   constexpr int HID = 256;
   __shared__ __attribute__((aligned(16))) float te_all[4 * 32 * TLD];   // per wave: enc tile, rows = feature, cols = point
   __shared__ __attribute__((aligned(16))) float dos_all[4 * 64];        // per wave: dout [32 points][2]
@@ -518,7 +521,9 @@ __global__ __launch_bounds__(256, 4) void mlp_bwd_dw_kernel(const float* __restr
     load_enc_b(in, ps, ls, q, n, h, eb);
     float2 d;
     if (dout_plane) {  // wave-uniform
-      d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
+      d = make_float2(dout[qc], dout[dout_plane + qc]);
+      if (dout2) d = make_float2(dout2[qc] + d.x, dout2[dout_plane + qc] + d.y);
+      d = make_float2(d.x * mq, d.y * mq);
     } else {
       const float2 dv = *reinterpret_cast<const float2*>(dout + qc * 2);
       d = make_float2(dv.x * mq, dv.y * mq);
@@ -572,9 +577,11 @@ static size_t denc_smem(int hid) { return (size_t)(hid / 32) * 4 * 64 * 16 * 2 +
 
 // d enc only (din may NOT alias in: the dW kernel still needs the encoding)
 int launch_mlp_bwd_denc(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
-                        const float* w2, const float* dout, float* din, hipStream_t st, int64_t dout_plane) {
+                        const float* w2, const float* dout, float* din, hipStream_t st, int64_t dout_plane,
+                        const float* dout2) {
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+  IMMOCO_REQUIRE(dout2 == nullptr || dout_plane != 0, "mlp_bwd_denc: a second dout addend needs the planar layout");
   IMMOCO_REQUIRE(cfg.n_hidden == 256 && in != din, "mlp_bwd_denc: the split backward is built for the 256-wide net, out of place");
   const int64_t n_tiles = cdiv(n, 32);
   // 2 workgroups per CU at most (66 KB of LDS each); a workgroup's fragment build is amortised over its tiles
@@ -588,7 +595,7 @@ int launch_mlp_bwd_denc(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));                   \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    mlp_bwd_denc_kernel<256, A><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, n_tiles, dout_plane);        \
+    mlp_bwd_denc_kernel<256, A><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, n_tiles, dout_plane, dout2); \
   } while (0)
   if (cfg.activation == IMMOCO_ACT_TANH) IMMOCO_DENC(IMMOCO_ACT_TANH);
   else IMMOCO_DENC(IMMOCO_ACT_RELU);
@@ -599,17 +606,19 @@ int launch_mlp_bwd_denc(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
 
 // dW1 += ..., dW2 += ... (atomics into the caller's gradient buffers, like the fused kernel)
 int launch_mlp_bwd_dw(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, int64_t ls, int64_t n, const float* w1,
-                      const float* w2, const float* dout, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane) {
+                      const float* w2, const float* dout, float* dw1, float* dw2, hipStream_t st, int64_t dout_plane,
+                      const float* dout2) {
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+  IMMOCO_REQUIRE(dout2 == nullptr || dout_plane != 0, "mlp_bwd_dw: a second dout addend needs the planar layout");
   IMMOCO_REQUIRE(cfg.n_hidden == 256, "mlp_bwd_dw: the split backward is built for the 256-wide net");
   const int64_t n_tiles = cdiv(n, 32);
   // grid.y: the two halves of the hidden layer; every workgroup flushes 16 KB of atomics once
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, 384), 2);
   if (cfg.activation == IMMOCO_ACT_TANH)
-    mlp_bwd_dw_kernel<IMMOCO_ACT_TANH><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, dout, dw1, dw2, n_tiles, dout_plane);
+    mlp_bwd_dw_kernel<IMMOCO_ACT_TANH><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, dout, dw1, dw2, n_tiles, dout_plane, dout2);
   else
-    mlp_bwd_dw_kernel<IMMOCO_ACT_RELU><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, dout, dw1, dw2, n_tiles, dout_plane);
+    mlp_bwd_dw_kernel<IMMOCO_ACT_RELU><<<grid, 256, 0, st>>>(in, ps, ls, n, w1, w2, dout, dw1, dw2, n_tiles, dout_plane, dout2);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

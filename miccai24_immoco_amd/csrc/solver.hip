@@ -31,6 +31,8 @@ struct Step {
   int branch = 0;
   int group = 2;  // 0 image forward, 1 motion forward, 2 serial middle (.. motion MLP backward), 3 motion encode
                   // backward, 4 image backward (MLP, encode, Adam), 5 tick, 6 motion Adam
+  int signal = -1;  // forked execution: record cross-branch event ev_x[signal] after this step on its stream ...
+  int wait = -1;    // ... make this step's stream wait for ev_x[wait] first (a dependency between the two branches)
 };
 
 }  // namespace immoco
@@ -66,6 +68,7 @@ struct immoco_solver {
   hipStream_t stream = nullptr, side = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   hipEvent_t ev_fj[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_x[2] = {nullptr, nullptr};   // cross-branch dependencies inside a fork (Step::signal / Step::wait)
   // timing markers around the dominant kernel (motion_encode_bwd) INSIDE the replayed graph, so that
   // bench.py's roofline figure is measured under the same conditions as the timed run
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
@@ -180,6 +183,11 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   }
   };
   auto push_image_fwd = [&] {
+  if (s->pruned && split_image_bwd(s->cfg) && backward && nM > 0)   // (= early_img below) the warp backward's dL/dimage share
+    st.push_back({"zero_dimage_warp", [=](hipStream_t q) {
+                    IMMOCO_CHECK_HIP(hipMemsetAsync(s->dimage_w, 0, (size_t)P * 8, q));
+                    return IMMOCO_OK;
+                  }, 2});
   st.push_back({"image_encode_fwd", [=](hipStream_t q) {
                   if (s->cfg.table_fp16)
                     return launch_hashgrid_fwd_half(s->lv_img, li, P, s->shadow_img, s->enc_img, e_ps, e_ls_i, q, act16);
@@ -204,6 +212,13 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     push_image_fwd();
   }
   const bool pruned = s->pruned;
+  // Pruned path with the split wide-MLP backward: the image branch of the second fork starts right after the column
+  // adjoint - the unwarped image's adjoint rows and the gradient-entropy term (three small kernels that each waited
+  // 25-50 us for a slot once the encode backward's 6000 workgroups were queued: profiles/r04_timeline_split_*.txt) run
+  // beside the warp backward instead, dL/dimage = [sign*adj0 + lambda dGE] + [the warp backward's share] is summed where
+  // the MLP backward kernels load it (two planar addends), and the warp's accumulation buffer is cleared at the start
+  // of the next image forward.
+  const bool early_img = pruned && split_image_bwd(s->cfg) && backward && nM > 0;
   float* zt0 = s->fft_t + 2 * P;   // pruned path: the adjoint seed of the unwarped image (its own columns only), [W][H]
   if (pruned) {
     // warp + row DFT of every motion image's own columns -> Z; ONE column transform; the select is implicit
@@ -256,7 +271,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                                         s->pr_off, nM, H, W, s->dimage_w, s->o_mot, q);
                     return launch_motion_warp_bwd(s->image, s->t_mot, s->xs, s->ys, slot1, nM, H, W, s->dimage,
                                                   s->o_mot, q);
-                  }});
+                  }, early_img ? 1 : 0});
+    if (early_img) st.back().signal = 0;   // the image branch's MLP backward waits for it
     st.push_back({"motion_mlp_bwd", [=](hipStream_t q) {
                     if (s->cfg.mlp_fp16 == 2)
                       return launch_mlp_bwd_bf16x2(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
@@ -266,7 +282,7 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                                                 s->enc_mot, g_w1m, g_w2m, q, 0, TCNN_LOSS_SCALE, act16);
                     return launch_mlp_bwd(s->cfg.motion_mlp, s->enc_mot, 2, 2 * NP, NP, w1m, w2m, s->o_mot,
                                           s->enc_mot, g_w1m, g_w2m, q);
-                  }, fork_early ? 1 : 0});  // "late": before the fork, the image chain's MFMA-bound MLP backward
+                  }, (fork_early || early_img) ? 1 : 0});  // "late": before the fork, the image chain's MFMA-bound MLP backward
                         // then runs beside the gather-bound encode backward instead of beside this MFMA-bound kernel (-1 %)
   }
   // Second fork: which chain is captured (and therefore starts) first.  "motion" (default in fp32): the 448-register
@@ -300,25 +316,33 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                     int rc = launch_keep_group0_cols(s->fft_t, b.col_group, nM, H, W, zt0, q);
                     return rc ? rc : fft_rows_adj_from_t(zt0, s->fftbuf, H, W, q);
                   }, 2});
-    st.push_back({"image_grad_init_ge_late", [=](hipStream_t q) {
-                    return launch_image_grad_init_after_warp(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
-                                                             b.loss_hist, s->dimage, s->dimage_w, q);
-                  }, 2});
+    if (early_img)   // beside the warp backward: dimage = sign*adj0 + lambda dGE (the warp's share stays in dimage_w)
+      st.push_back({"image_grad_init_ge_early", [=](hipStream_t q) {
+                      return launch_image_grad_init(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev, b.loss_hist,
+                                                    s->dimage, q);
+                    }, 2});
+    else
+      st.push_back({"image_grad_init_ge_late", [=](hipStream_t q) {
+                      return launch_image_grad_init_after_warp(s->image, s->fftbuf, H, W, s->lambda_dev, s->iter_dev,
+                                                               b.loss_hist, s->dimage, s->dimage_w, q);
+                    }, 2});
   }
   if (split_image_bwd(s->cfg)) {
+    const float* d2 = early_img ? s->dimage_w : nullptr;   // second planar addend of dL/dimage
     st.push_back({"image_mlp_bwd_denc", [=](hipStream_t q) {
                     if (s->cfg.mlp_fp16)
                       return launch_mlp_bwd_f16_split(s->cfg.image_mlp, 1, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->dimage,
-                                                      s->denc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16);
+                                                      s->denc_img, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16, d2);
                     return launch_mlp_bwd_denc(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, s->denc_img, q,
-                                               /*planar dimage*/ P);
+                                               /*planar dimage*/ P, d2);
                   }, 2});
+    if (early_img) st.back().wait = 0;   // the warp backward (other branch) has added its share
     st.push_back({"image_mlp_bwd_dw", [=](hipStream_t q) {
                     if (s->cfg.mlp_fp16)
                       return launch_mlp_bwd_f16_split(s->cfg.image_mlp, 2, s->enc_img, e_ps, e_ls_i, P, w1i, w2i, s->dimage,
-                                                      nullptr, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16);
+                                                      nullptr, g_w1i, g_w2i, q, /*planar dimage*/ P, TCNN_LOSS_SCALE, act16, d2);
                     return launch_mlp_bwd_dw(s->cfg.image_mlp, s->enc_img, 2, 2 * P, P, w1i, w2i, s->dimage, g_w1i, g_w2i, q,
-                                             /*planar dimage*/ P);
+                                             /*planar dimage*/ P, d2);
                   }, 2});
     return;
   }
@@ -383,11 +407,13 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
                 }});
   for (Step& x : st) {
     const std::string n = x.name;
-    x.group = (n == "image_encode_fwd" || n == "image_mlp_fwd" || n == "image_to_fft_slot" || n == "image_rows_fft") ? 0
+    x.group = (n == "image_encode_fwd" || n == "image_mlp_fwd" || n == "image_to_fft_slot" || n == "image_rows_fft" ||
+               n == "zero_dimage_warp")                                                          ? 0
               : (n == "motion_encode_fwd" || n == "motion_mlp_fwd")                             ? 1
               : n == "motion_encode_bwd"                                                        ? 3
               : (n == "image_mlp_bwd" || n == "image_mlp_bwd_denc" || n == "image_mlp_bwd_dw" || n == "image_encode_bwd" ||
-                 n == "adam_image" || n == "image_adjoint_rows" || n == "image_grad_init_ge_late")  ? 4
+                 n == "adam_image" || n == "image_adjoint_rows" || n == "image_grad_init_ge_late" ||
+                 n == "image_grad_init_ge_early")                                               ? 4
               : n == "tick"                                                                     ? 5
               : n == "adam_motion"                                                              ? 6
                                                                                                 : 2;
@@ -565,8 +591,10 @@ int run_steps_forked(immoco_solver* s, const std::vector<Step>& steps, hipStream
     if (mark) IMMOCO_CHECK_HIP(hipEventRecord(s->ev_k0, sq));
     int rc;
     if (hook && (rc = (*hook)(st, sq, true))) return rc;
+    if (st.wait >= 0 && forked) IMMOCO_CHECK_HIP(hipStreamWaitEvent(sq, s->ev_x[st.wait], 0));
     rc = st.run(sq);
     if (rc) return rc;
+    if (st.signal >= 0 && forked) IMMOCO_CHECK_HIP(hipEventRecord(s->ev_x[st.signal], sq));
     if (hook && (rc = (*hook)(st, sq, false))) return rc;
     if (mark) {
       IMMOCO_CHECK_HIP(hipEventRecord(s->ev_k1, sq));
@@ -663,6 +691,7 @@ extern "C" int immoco_solver_create(const immoco_solver_cfg* cfg, immoco_solver_
   // (a high- or low-priority side stream makes the iteration 7 % slower - 1.71 vs 1.60 ms - whichever way)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking);
   for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ev_fj[i], hipEventDisableTiming);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ev_x[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&s->ev_k0);
   if (e == hipSuccess) e = hipEventCreate(&s->ev_k1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
@@ -728,6 +757,8 @@ extern "C" int immoco_solver_destroy(immoco_solver_t s) {
   if (s->ev_in) hipEventDestroy(s->ev_in);
   if (s->ev_out) hipEventDestroy(s->ev_out);
   for (hipEvent_t ev : s->ev_fj)
+    if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : s->ev_x)
     if (ev) hipEventDestroy(ev);
   if (s->ev_k0) hipEventDestroy(s->ev_k0);
   if (s->ev_k1) hipEventDestroy(s->ev_k1);

@@ -430,6 +430,16 @@ class _MLPHalf(torch.autograd.Function):
         return denc / S, (dp16.t() @ e16) / S, (d16.t() @ h16) / S, None, None, None
 
 
+def tanh_alt(x: torch.Tensor) -> torch.Tensor:
+    """An equally valid fp32 tanh: 1 - 2 / (exp(2|x|) + 1) with x - x^3/3 below 0.04 (the formula of the HIP kernels,
+    csrc/mlp_mfma.hip:tanh_fast, evaluated with torch's exp) - differs from torch.tanh by ~1e-7.  Used by the sensitivity
+    experiment of DESIGN.md 2.4 only (OracleINR(tanh="alt")): does an O(1e-7) detail of the ORACLE move its own PSNR level?"""
+    ax = x.abs()
+    big = 1.0 - 2.0 / (torch.exp(2.0 * ax) + 1.0)
+    small = ax * (1.0 - ax * ax * 0.33333334)
+    return torch.where(ax < 0.04, small, big) * torch.sign(x)
+
+
 class OracleINR(torch.nn.Module):
     """Stand-in for tinycudann.NetworkWithInputEncoding(n_in, n_out, enc_cfg, net_cfg)
     (call sites immoco.py:60-65,85,93) in fp32 on the CPU.  One flat `params`
@@ -437,8 +447,9 @@ class OracleINR(torch.nn.Module):
     first forward (the reference always passes the same grid)."""
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False,
-                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True, device=None):
+                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True, device=None, tanh="torch"):
         super().__init__()
+        self.tanh = tanh_alt if tanh == "alt" else torch.tanh
         # device != cpu: the DEVICE ORACLE (ATen kernels only; HashGridPlan.encode_device) - the fast sampler
         # of the statistical parity fixtures (tools/device_oracle_sampler.py); validated against the CPU oracle
         # by tests/test_gpu_ops.py::test_device_oracle_vs_cpu_oracle_teacher_forced
@@ -503,7 +514,7 @@ class OracleINR(torch.nn.Module):
             out = _MLPHalf.apply(enc, w1, w2, self.mlp.activation, self.loss_scale, self.denc_fp16)
         else:
             pre = enc @ w1.t()
-            h = torch.relu(pre) if self.mlp.activation == "relu" else torch.tanh(pre)
+            h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)
             out = h @ w2.t()
         if perm is not None:
             out = torch.empty_like(out).index_copy(0, perm, out)
@@ -611,7 +622,7 @@ class OracleIMMoCo(torch.nn.Module):
         o = self.image_inr(self.identy_grid.view(-1, 2)).float().view(H, W, 2)
         image_prior = o[..., 0] + 1j * o[..., 1]
         images = image_prior.squeeze().unsqueeze(0).repeat(nM, 1, 1)
-        grids = self.motion_inr(self.input_grid).float().tanh().view(nM, H, W, 2) \
+        grids = self.motion_inr.tanh(self.motion_inr(self.input_grid).float()).view(nM, H, W, 2) \
             + self.identy_grid.view(1, H, W, 2)
         masks = self.masks
         if self._group_perm is not None:      # same terms, another order of the group axis

@@ -37,8 +37,9 @@ def main():
         g = np.load(os.path.join(ROOT, "tests", "golden", "c2_slice1_input.npz"))
         k, lines = torch.from_numpy(g["kspace"]).to(dev), torch.from_numpy(g["lines"]).to(dev)
     else:
-        s = synth.make_slice(320, 320, 10, a.slice, device=dev)     # same corruption as oracle/synth_cpu (tested)
-        k, lines = s["kspace"], s["lines"]
+        from oracle import synth_cpu          # the device-oracle draws' own input (CPU generator), bit for bit
+        s = synth_cpu.make_slice(320, 320, 10, a.slice)
+        k, lines = s["kspace"].to(dev), s["lines"].to(dev)
     masks = pkg.extract_movement_groups(lines, make_list=True)
     gt = synth.phantom(320, 320, 1000 + a.slice).abs()
     sol = get_solver(dev, 320, 320, int(masks.shape[0]), mlp_fp16={"f32": 0, "f16mlp": 1, "bf16x2": 2}[a.precision])

@@ -13,7 +13,9 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
 traffic_name = tag.split("_")[0] + "_traffic.json"      # r02_final -> profiles/r02_traffic.json (read by bench.py)
-PHASE = [("hashgrid_fwd_kernel<2", "image_encode_fwd"), ("hashgrid_fwd_kernel<3", "motion_encode_fwd"),
+PHASE = [("mlp_bwd_denc_kernel", "image_mlp_bwd_denc"), ("mlp_bwd_dw_kernel", "image_mlp_bwd_dw"),
+         ("motion_warp_dft_kernel", "motion_warp_dft"), ("motion_warp_bwd_dft_kernel", "motion_warp_bwd"),
+         ("hashgrid_fwd_kernel<2", "image_encode_fwd"), ("hashgrid_fwd_kernel<3", "motion_encode_fwd"),
          ("mlp_fwd_mfma_kernel<256", "image_mlp_fwd"), ("mlp_fwd_mfma_kernel<64", "motion_mlp_fwd"),
          ("mlp_fwd_f16_kernel<256", "image_mlp_fwd"), ("mlp_fwd_f16_kernel<64", "motion_mlp_fwd"),
          ("mlp_bwd_f16_kernel<256", "image_mlp_bwd"), ("mlp_bwd_f16_kernel<64", "motion_mlp_bwd"),
