@@ -441,8 +441,10 @@ __global__ __launch_bounds__(256) void motion_warp_bwd_tiled_i64_kernel(const fl
 // implicit.  The adjoint runs backwards: column transform, then adj_m[r][w] = sum_{c in C_m} Zadj[c][r] e^{+2 pi i w c / W}
 // evaluated inside the warp backward.  Per iteration this replaces 10 of 11 2-D transforms each way and the 8 MB
 // warp-output / adjoint-input round trips by W^2 H complex multiply-adds (0.26 GFLOP at 320 x 320, whatever the masks).
-constexpr int DFT_ROWS = 4;   // rows of one motion image per workgroup of the forward kernel
-
+// DFT_ROWS rows of one motion image per workgroup of the forward kernel.  The warp part is latency-bound (o -> tanh ->
+// four image gathers per pixel), so fewer pixels per thread win: 320x320x10 isolated 0.0226 ms with 4 rows (5 pixels
+// per thread), 0.0193 ms with 2 rows, 0.0202 ms with 1 (IMMOCO_DFT_ROWS in the diagnostics build).
+template <int DFT_ROWS>
 __global__ __launch_bounds__(256) void motion_warp_dft_kernel(const float2* __restrict__ img, const float2* __restrict__ o,
                                                               const float* __restrict__ xs, const float* __restrict__ ys,
                                                               int H, int W, const float2* __restrict__ tw_g,
@@ -497,19 +499,27 @@ int launch_motion_warp_dft(const float* image, const float* o, const float* xs, 
                            const float* tw, const int32_t* cols, const int32_t* off, float* t_out, float* zt,
                            hipStream_t st) {
   if (nM == 0) return IMMOCO_OK;
-  dim3 grid((unsigned)cdiv(H, DFT_ROWS), (unsigned)nM);
-  const size_t smem = (size_t)(DFT_ROWS + 1) * W * sizeof(float2);
+  static const int rows_env = [] { const char* e = immoco_diag_env("IMMOCO_DFT_ROWS"); return e ? atoi(e) : 0; }();
+  const int rows = (rows_env == 1 || rows_env == 2 || rows_env == 4) ? rows_env : 2;   // measured: 4 rows 0.0230, 2 rows 0.0193, 1 row 0.0202 ms
+  dim3 grid((unsigned)cdiv(H, rows), (unsigned)nM);
+  const size_t smem = (size_t)(rows + 1) * W * sizeof(float2);
   IMMOCO_REQUIRE(smem <= 64 * 1024, "motion_warp_dft: image width %d too large for the row tile", W);
-  motion_warp_dft_kernel<<<grid, 256, smem, st>>>((const float2*)image, (const float2*)o, xs, ys, H, W, (const float2*)tw,
-                                                  cols, off, (float2*)t_out, (float2*)zt);
+#define IMMOCO_WDFT(R)                                                                                                  \
+  motion_warp_dft_kernel<R><<<grid, 256, smem, st>>>((const float2*)image, (const float2*)o, xs, ys, H, W, (const float2*)tw, \
+                                                     cols, off, (float2*)t_out, (float2*)zt)
+  if (rows == 1) IMMOCO_WDFT(1);
+  else if (rows == 2) IMMOCO_WDFT(2);
+  else IMMOCO_WDFT(4);
+#undef IMMOCO_WDFT
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }
 
 // Backward: motion_warp_bwd_tiled_i64_kernel with the adjoint row DFT evaluated on the fly (16 x 16 pixel tile x a
 // chunk of at most two motion groups).  zc[rr][jj] stages Zadj[c_j][r0 + rr] of 32 columns at a time.
-constexpr int BWD_MPC = 2, BWD_CC = 32;
+constexpr int BWD_CC = 32;
 
+template <int BWD_MPC>
 __global__ __launch_bounds__(256) void motion_warp_bwd_dft_kernel(const float2* __restrict__ img,
                                                                   const float2* __restrict__ t_in,
                                                                   const float* __restrict__ xs,
@@ -662,11 +672,19 @@ int launch_motion_warp_bwd_dft(const float* image, const float* t, const float* 
                                float* dimage_planar, float* d_o, hipStream_t st) {
   if (nM == 0) return IMMOCO_OK;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-  dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)cdiv(nM, BWD_MPC));
-  const int tbits = 62 - 8 - 1 - 1;   // 256 pixels x 2 groups of < 2^(tbits + 1) each
-  motion_warp_bwd_dft_kernel<<<grid, 256, (size_t)W * sizeof(float2), st>>>(
-      (const float2*)image, (const float2*)t, xs, ys, (const float2*)zt_adj, (const float2*)tw, cols, off, nM, H, W,
-      tiles_x, tbits, dimage_planar, (float2*)d_o);
+  // motion groups per workgroup: 2 (0.0325 ms; 1 group: 0.0383 ms; IMMOCO_BWD_MPC in the diagnostics build)
+  static const int mpc_env = [] { const char* e = immoco_diag_env("IMMOCO_BWD_MPC"); return e ? atoi(e) : 0; }();
+  const int mpc = mpc_env == 1 ? 1 : 2;
+  dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)cdiv(nM, mpc));
+  const int tbits = 62 - 8 - 1 - 1;   // 256 pixels x <= 2 groups of < 2^(tbits + 1) each
+  if (mpc == 1)
+    motion_warp_bwd_dft_kernel<1><<<grid, 256, (size_t)W * sizeof(float2), st>>>(
+        (const float2*)image, (const float2*)t, xs, ys, (const float2*)zt_adj, (const float2*)tw, cols, off, nM, H, W,
+        tiles_x, tbits, dimage_planar, (float2*)d_o);
+  else
+    motion_warp_bwd_dft_kernel<2><<<grid, 256, (size_t)W * sizeof(float2), st>>>(
+        (const float2*)image, (const float2*)t, xs, ys, (const float2*)zt_adj, (const float2*)tw, cols, off, nM, H, W,
+        tiles_x, tbits, dimage_planar, (float2*)d_o);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
 }

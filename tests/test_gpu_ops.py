@@ -940,7 +940,10 @@ def test_teacher_forced_state_c2_shape(env, K):
     if K > 5:
         record = _oracle_step_from_state(orc, _device_oracle_state(orc, s["kspace"], masks, 3000, K), masks, K)
     rep = _teacher_forced_step(pkg, L, orc, s["kspace"], masks, 3000, K, record=record)
-    _device_oracle_step(orc, rep["_oracle_record"], masks, K)        # the sampler at K = 5 / 200 too
+    # the sampler at K = 5 / 200 too.  At K = 200 the image net's gradient is a residual of cancelling
+    # terms: the device oracle (rocBLAS GEMMs, ATen kernels) sits 1.2e-4 (rel. L2) / 2.1e-4 (largest entry) from the CPU
+    # oracle there - HIP itself 4.4e-6 - so the bound for that state is 5e-4; K = 5: 1e-4 (measured 2e-6 / 4e-5)
+    _device_oracle_step(orc, rep["_oracle_record"], masks, K, grad_tol=1e-4 if K <= 5 else 5e-4)
     # measured, K = 5: gradient rel. L2 6e-7 (image) / 7e-6 (motion), largest update difference 4.0e-6 = 4e-4 * lr;
     # K = 200: 2.7e-6 / 1.8e-5, update difference 2.5e-5 on 10 of 9.45 M entries (Adam turns a cancelling-sum gradient
     # into a +-lr step: a handful of entries may differ by a few 1e-3 * lr there)
