@@ -350,6 +350,142 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_lat3_kernel(Levels lv, Latti
   }
 }
 
+// Round 4: a software-PIPELINED variant of the one-point kernel.  A thread walks K points of one level (256 apart); the
+// gathers of point k + 1 are issued BEFORE point k's are consumed and its encoding is stored, so a wave always has one
+// point's gathers in flight while it interpolates and stores the previous one - the round-2 loops (compute, load, wait,
+// combine, store, next) drained the memory pipe at every store (vector-memory results return in issue order) and were
+// slower than fresh waves.  Whether the dim-0 corner pairs are aligned slot pairs (one 16-byte load per pair) is
+// decided once per WORKGROUP from its first and last point (dim 0 is the motion group: constant over the workgroup's
+// contiguous points unless it straddles two groups), which keeps each path straight-line code.  Same arithmetic per
+// point: bit-identical.
+// MEASURED (MI355X, 320x320x10, isolated): one-point kernel 0.2528 ms; K = 2: 0.2528, K = 4: 0.2697, K = 8: 0.3393 ms (the ISA
+// does keep point k + 1's eight gathers in flight while point k is consumed: s_waitcnt vmcnt(15) ... (8)).  Longer-lived
+// waves lose even when pipelined - a dead end like the round-2 loops; the kernel stays behind IMMOCO_FWD_PIPE in the
+// diagnostics build only.
+// (Specialised for power-of-two level sizes - the reference's configuration - and lattices below 2^24 points, so that
+// the per-point code has no branches at all: scalar branches at every corner would put a wait at every join.)
+__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t d, float inv_d) {   // n / d for n, d < 2^24
+  uint32_t q = (uint32_t)((float)n * inv_d);
+  q -= (q * d > n) ? 1u : 0u;
+  q += ((q + 1u) * d <= n) ? 1u : 0u;
+  return q;
+}
+
+// The lattice axes are staged in LDS (`ax`: axis 0, then 1, then 2): a coordinate load from global memory would share
+// the vector-memory counter with the gathers - its wait would drain the previous point's gathers and undo the pipeline.
+template <int K, bool MERGED, bool HASHED, bool HALF>
+__device__ __forceinline__ void fwd_pipe_body(const Levels& lv, const Lattice& lat, const float* ax, int64_t n, int l,
+                                              const float2* __restrict__ tab, float* __restrict__ enc, int64_t ps,
+                                              int64_t ls, int64_t p0) {
+  constexpr int NC = 8;
+  const float scale = lv.scale[l];
+  const uint32_t mask = lv.size[l] - 1u, res = lv.res[l];
+  // dense levels: idx = c0 + c1 res + c2 res^2 with the uint32 stride walk of grid_index() (a stride that has wrapped
+  // to 0 or exceeds the level size drops the remaining dimensions)
+  uint32_t st1 = 0u, st2 = 0u;
+  {
+    uint32_t stride = 1u;
+    if (stride <= lv.size[l]) stride *= res;               // after dim 0
+    if (stride <= lv.size[l]) { st1 = stride; stride *= res; }
+    if (stride <= lv.size[l]) st2 = stride;
+  }
+  const uint32_t s0 = (uint32_t)lat.stride[0], s1 = (uint32_t)lat.stride[1];
+  const float inv_s0 = 1.0f / (float)s0, inv_s1 = 1.0f / (float)s1;
+  uint32_t idx[2][NC];
+  float wgt[2][NC];
+  float4 q4[2][NC / 2];   // MERGED: one aligned slot pair per dim-0 corner pair
+  float2 q2[2][NC];       // else: one slot per corner
+  auto prepare = [&](int buf, int64_t p) {
+    const uint32_t q = (uint32_t)(p < n ? p : n - 1);   // tail lanes recompute the last point (never stored)
+    const uint32_t i0 = div_small(q, s0, inv_s0), rem = q - i0 * s0, i1 = div_small(rem, s1, inv_s1);
+    const float x[3] = {ax[i0], ax[lat.n[0] + i1], ax[lat.n[0] + lat.n[1] + (rem - i1 * s1)]};
+    uint32_t cell[3];
+    float fr[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pos_fract(x[d], scale, cell[d], fr[d]);
+#pragma unroll
+    for (int corner = 0; corner < NC; ++corner) {
+      uint32_t c[3];
+      float w = 1.0f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const bool hi = (corner >> d) & 1;
+        c[d] = cell[d] + (hi ? 1u : 0u);
+        w = mul_nc(w, hi ? fr[d] : sub_nc(1.0f, fr[d]));
+      }
+      const uint32_t raw = HASHED ? (c[0] ^ (c[1] * IMMOCO_PRIME1) ^ (c[2] * IMMOCO_PRIME2)) : (c[0] + c[1] * st1 + c[2] * st2);
+      idx[buf][corner] = raw & mask;
+      wgt[buf][corner] = w;
+    }
+    if (MERGED) {
+#pragma unroll
+      for (int pair = 0; pair < NC / 2; ++pair)
+        q4[buf][pair] = *reinterpret_cast<const float4*>(tab + (idx[buf][2 * pair] & ~1u));
+    } else {
+#pragma unroll
+      for (int corner = 0; corner < NC; ++corner) q2[buf][corner] = tab[idx[buf][corner]];
+    }
+  };
+  auto finish = [&](int buf, int64_t p) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < NC; ++corner) {
+      float2 v;
+      if (MERGED) {
+        const float4 q = q4[buf][corner >> 1];
+        const bool odd = idx[buf][corner & ~1] & 1u;          // the pair's low corner sits in the odd slot
+        const bool take_hi = ((corner & 1) != 0) != odd;       // low corner: lo unless odd; high corner: hi unless odd
+        v = take_hi ? make_float2(q.z, q.w) : make_float2(q.x, q.y);
+      } else {
+        v = q2[buf][corner];
+      }
+      const float t0 = mul_nc(v.x, wgt[buf][corner]), t1 = mul_nc(v.y, wgt[buf][corner]);
+      a0 = corner == 0 ? t0 : add_nc(a0, t0);
+      a1 = corner == 0 ? t1 : add_nc(a1, t1);
+    }
+    if (p < n) store_enc(enc + p * ps + (int64_t)l * ls, make_float2(a0, a1), HALF ? (16 | 2) : 2);   // non-temporal
+  };
+  prepare(0, p0);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k + 1 < K) prepare((k + 1) & 1, p0 + (int64_t)(k + 1) * 256);
+    finish(k & 1, p0 + (int64_t)k * 256);
+  }
+}
+
+template <int K, bool HALF>
+__global__ __launch_bounds__(256) void hashgrid_fwd_pipe_kernel(Levels lv, Lattice lat, int64_t n,
+                                                                const float2* __restrict__ table,
+                                                                float* __restrict__ enc, int64_t ps, int64_t ls) {
+  extern __shared__ float ax[];   // the three lattice axes
+  const int l = blockIdx.y;
+  const int n01 = lat.n[0] + lat.n[1], n012 = n01 + lat.n[2];
+  for (int i = threadIdx.x; i < n012; i += 256)
+    ax[i] = i < lat.n[0] ? lat.axis[0][i] : (i < n01 ? lat.axis[1][i - lat.n[0]] : lat.axis[2][i - n01]);
+  __syncthreads();
+  const float2* __restrict__ tab = table + lv.offset[l];
+  const int64_t first = (int64_t)blockIdx.x * K * 256, p0 = first + threadIdx.x;
+  const bool hashed = (lv.hashed >> l) & 1u;
+  // aligned-pair test for the workgroup's first and last point: the two dim-0 corners differ in bit 0 only <=> the
+  // dim-0 cell is even (dense levels: stride 1 for dim 0; hashed levels: prime 1 for dim 0; sizes are powers of two)
+  auto even_cell = [&](int64_t p) {
+    const uint32_t q = (uint32_t)(p < n ? p : n - 1);
+    const uint32_t i0 = q / (uint32_t)lat.stride[0];
+    uint32_t cell;
+    float fr;
+    pos_fract(ax[i0], lv.scale[l], cell, fr);
+    return (cell & 1u) == 0u;
+  };
+  const bool merged = lv.size[l] >= 2u && even_cell(first) && even_cell(first + (int64_t)K * 256 - 1);   // workgroup-uniform
+  if (merged) {
+    if (hashed) fwd_pipe_body<K, true, true, HALF>(lv, lat, ax, n, l, tab, enc, ps, ls, p0);
+    else fwd_pipe_body<K, true, false, HALF>(lv, lat, ax, n, l, tab, enc, ps, ls, p0);
+  } else {
+    if (hashed) fwd_pipe_body<K, false, true, HALF>(lv, lat, ax, n, l, tab, enc, ps, ls, p0);
+    else fwd_pipe_body<K, false, false, HALF>(lv, lat, ax, n, l, tab, enc, ps, ls, p0);
+  }
+}
+
 // Points per thread in the lattice kernel.  Measured (MI355X): 320x320x10 (1.0 M points): K = 1 0.262, K = 2 0.276,
 // K = 4 0.313 ms - the occupancy lost to the extra registers (8 -> 5 -> 3 waves/SIMD) costs more than the overlap
 // brings; 640x640x20 (8.2 M points): K = 1 1.77, K = 2 1.62 ms.  So: 2 from 4 M points on, else the one-point
@@ -436,6 +572,26 @@ int launch_hashgrid_fwd(const Levels& lv, const float* coords, const Lattice* la
   }
   const int mode = enc_store_sc1() | (half_out ? 16 : 0);
   const float2* t = reinterpret_cast<const float2*>(table);
+  // software-pipelined walk over K points per thread (3-D lattices; A/B switch IMMOCO_FWD_PIPE = 0 | 2 | 4 | 8)
+  static const int pipe_env = [] { const char* e = immoco_diag_env("IMMOCO_FWD_PIPE"); return e ? atoi(e) : -1; }();
+  const int pipe = pipe_env >= 0 ? pipe_env : 0;
+  const bool all_pow2 = lv.pow2 == ((lv.n_levels >= 32 ? 0u : (1u << lv.n_levels)) - 1u);
+  if (lat && lv.dims == 3 && (pipe == 2 || pipe == 4 || pipe == 8) && n >= 256 * 64 && n < (1 << 24) && all_pow2) {
+    dim3 g((unsigned)cdiv(n, 256 * pipe), lv.n_levels);
+    const size_t sm = (size_t)(L.n[0] + L.n[1] + L.n[2]) * sizeof(float);
+    IMMOCO_REQUIRE(sm <= 48 * 1024, "hashgrid_fwd: lattice axes too long for the LDS copy");
+#define IMMOCO_PIPE(KK)                                                                                    \
+  do {                                                                                                     \
+    if (half_out) hashgrid_fwd_pipe_kernel<KK, true><<<g, 256, sm, st>>>(lv, L, n, t, enc, ps, ls);        \
+    else hashgrid_fwd_pipe_kernel<KK, false><<<g, 256, sm, st>>>(lv, L, n, t, enc, ps, ls);                \
+  } while (0)
+    if (pipe == 2) IMMOCO_PIPE(2);
+    else if (pipe == 4) IMMOCO_PIPE(4);
+    else IMMOCO_PIPE(8);
+#undef IMMOCO_PIPE
+    IMMOCO_LAUNCH_CHECK();
+    return IMMOCO_OK;
+  }
   if (lat && launch_fwd_lat3<float2>(lv, L, n, t, enc, ps, ls, st, mode)) {
     IMMOCO_LAUNCH_CHECK();
     return IMMOCO_OK;
