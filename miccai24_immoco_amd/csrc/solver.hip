@@ -82,7 +82,7 @@ struct immoco_solver {
   std::vector<std::string> phase_names;
   std::vector<float> phase_ms;
   // paired batch mode (cfg.batch_pair): events that order the two slices' gather kernels, the pair's graphs
-  hipEvent_t ev_pair[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_pair[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t pg1 = nullptr, pgk = nullptr;   // one / GK double-iterations
   std::vector<const void*> pkey;
   // batch lanes (immoco_solver_solve_batch): further workspaces that share this solver's lattices and plans
@@ -994,7 +994,7 @@ int solve_pair(immoco_solver* A, immoco_solver* B, const SliceArgs& a, const Sli
   struct Lists {
     std::vector<Step> img, e, n, c, d;   // image forward | E | N | C | D
     hipStream_t p;
-    hipEvent_t ev_pre, ev_e, ev_n, ev_c, ev_d;
+    hipEvent_t ev_pre, ev_e, ev_n, ev_c, ev_d, ev_m;   // ev_m: the motion Adam step is done (all the next E waits for)
   };
   auto make_lists = [](const std::vector<Step>& all, hipStream_t p, hipEvent_t* ev) {
     Lists l;
@@ -1008,48 +1008,69 @@ int solve_pair(immoco_solver* A, immoco_solver* B, const SliceArgs& a, const Sli
       for (const Step& st : all)
         if (st.group == g) l.d.push_back(st);
     l.p = p;
-    l.ev_pre = ev[0]; l.ev_e = ev[1]; l.ev_n = ev[2]; l.ev_c = ev[3]; l.ev_d = ev[4];
+    l.ev_pre = ev[0]; l.ev_e = ev[1]; l.ev_n = ev[2]; l.ev_c = ev[3]; l.ev_d = ev[4]; l.ev_m = ev[5];
     return l;
   };
-  const Lists LA = make_lists(build_steps(A, ba, true), A->side, A->ev_pair), LB = make_lists(build_steps(B, bb, true), B->side, A->ev_pair + 5);
-  // one double iteration; again: a previous double iteration of this capture / eager sequence has recorded ev_d
-  auto double_iteration = [&](bool again) -> int {
-    int r;
-    auto encode_fwd = [&](const Lists& l) -> int {   // q: [wait D(prev)] ; pre ; E ; record | p: wait pre ; img
-      if (again) IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, l.ev_d, 0));
-      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_pre, q));
-      IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_pre, 0));
-      int rr;
-      if ((rr = run_steps(l.img, l.p)) || (rr = run_steps(l.e, q))) return rr;
-      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_e, q));
-      return IMMOCO_OK;
-    };
-    auto middle = [&](const Lists& l) -> int {       // p: wait E ; N ; record
-      IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_e, 0));
-      int rr;
-      if ((rr = run_steps(l.n, l.p))) return rr;
-      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_n, l.p));
-      return IMMOCO_OK;
-    };
-    auto encode_bwd = [&](const Lists& l) -> int {   // q: wait N ; C ; record | p: wait C ; D ; record
-      IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, l.ev_n, 0));
-      int rr;
-      if ((rr = run_steps(l.c, q))) return rr;
-      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_c, q));
-      IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_c, 0));
-      if ((rr = run_steps(l.d, l.p))) return rr;
-      IMMOCO_CHECK_HIP(hipEventRecord(l.ev_d, l.p));
-      return IMMOCO_OK;
-    };
-    if ((r = encode_fwd(LA)) || (r = middle(LA)) || (r = encode_fwd(LB)) || (r = middle(LB)) || (r = encode_bwd(LA)) ||
-        (r = encode_bwd(LB)))
-      return r;
+  const Lists LA = make_lists(build_steps(A, ba, true), A->side, A->ev_pair), LB = make_lists(build_steps(B, bb, true), B->side, A->ev_pair + 6);
+  // One double iteration is  E_A N_A | E_B N_B | C_A D_A | C_B D_B.  Round 4: D_B (slice B's Adam steps and image backward
+  // chain, ~230 us) is CAPTURED after the next double iteration's E_A / N_A: rocprofv3 showed the replayed graph starting
+  // E_A(k+1) only after D_B(k)'s last kernel (profiles/r04_timeline_pair.txt: the gather stream idled 245 us per double
+  // iteration there) although E_A(k+1) depends on D_A(k) alone - the graph executor serialises branches in capture
+  // order.  With the rotated capture order E_A(k+1) runs beside D_B(k).
+  // The next motion encode forward needs the motion Adam step only (ev_m, recorded below), but waiting for just that
+  // is SLOWER: the forward gather then runs beside its own slice's image encode backward and Adam, whose streams push its
+  // level slices out of the XCD L2s (measured, batch 4: 1.113 -> 1.155 ms per slice-iteration in fp32, 0.892 -> 0.925 with
+  // fp16 MLPs).  It waits for the whole D (ev_d).
+  auto encode_fwd = [&](const Lists& l, bool again) -> int {   // q: [wait D(prev)] ; pre ; E ; record | p: wait pre ; img
+    if (again) IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, l.ev_d, 0));
+    IMMOCO_CHECK_HIP(hipEventRecord(l.ev_pre, q));
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_pre, 0));
+    int rr;
+    if ((rr = run_steps(l.img, l.p)) || (rr = run_steps(l.e, q))) return rr;
+    IMMOCO_CHECK_HIP(hipEventRecord(l.ev_e, q));
     return IMMOCO_OK;
   };
-  auto sequence = [&](int reps) -> int {
-    int r = IMMOCO_OK;
-    for (int k = 0; k < reps && r == IMMOCO_OK; ++k) r = double_iteration(k > 0);
-    if (r) return r;
+  auto middle = [&](const Lists& l) -> int {       // p: wait E ; N ; record
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_e, 0));
+    int rr;
+    if ((rr = run_steps(l.n, l.p))) return rr;
+    IMMOCO_CHECK_HIP(hipEventRecord(l.ev_n, l.p));
+    return IMMOCO_OK;
+  };
+  auto encode_bwd_c = [&](const Lists& l) -> int {   // q: wait N ; C ; record
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, l.ev_n, 0));
+    int rr;
+    if ((rr = run_steps(l.c, q))) return rr;
+    IMMOCO_CHECK_HIP(hipEventRecord(l.ev_c, q));
+    return IMMOCO_OK;
+  };
+  auto encode_bwd_d = [&](const Lists& l) -> int {   // p: wait C ; D ; record
+    IMMOCO_CHECK_HIP(hipStreamWaitEvent(l.p, l.ev_c, 0));
+    bool marked = false;
+    for (const Step& st : l.d) {
+      int rr = st.run(l.p);
+      if (rr) return rr;
+      if (!marked && st.group == 6) {   // the motion Adam step comes first in D
+        IMMOCO_CHECK_HIP(hipEventRecord(l.ev_m, l.p));
+        marked = true;
+      }
+    }
+    if (!marked) IMMOCO_CHECK_HIP(hipEventRecord(l.ev_m, l.p));
+    IMMOCO_CHECK_HIP(hipEventRecord(l.ev_d, l.p));
+    return IMMOCO_OK;
+  };
+  // `again`: an earlier double iteration of THIS capture / eager sequence has recorded the ev_d events (a captured
+  // stream may not wait for an event recorded outside the capture; between launches the join below orders everything)
+  auto sequence = [&](int reps, bool again0 = false) -> int {
+    int r;
+    if ((r = encode_fwd(LA, again0)) || (r = middle(LA))) return r;
+    for (int k = 0; k < reps; ++k) {
+      if ((r = encode_fwd(LB, again0 || k > 0)) || (r = middle(LB)) || (r = encode_bwd_c(LA)) || (r = encode_bwd_d(LA)) ||
+          (r = encode_bwd_c(LB)))
+        return r;
+      if (k + 1 < reps && ((r = encode_fwd(LA, true)) || (r = middle(LA)))) return r;   // E_A(k+1) ahead of D_B(k)
+      if ((r = encode_bwd_d(LB))) return r;
+    }
     IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, LA.ev_d, 0));   // both side streams join the origin
     IMMOCO_CHECK_HIP(hipStreamWaitEvent(q, LB.ev_d, 0));
     return IMMOCO_OK;
