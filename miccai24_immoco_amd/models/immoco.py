@@ -358,7 +358,7 @@ def imcoco_motion_correction(kspace_corr, masks, iters=200, learning_rate=1e-2, 
 
 def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate=1e-2, lambda_ge=1e-2, *, seed=1337,
                                    norm_scale=16000.0, lambda_rule="immoco", return_loss=False, use_graph=True,
-                                   table_fp16=False, lanes=1, mlp_fp16=False, pair=False):
+                                   table_fp16=False, lanes=1, mlp_fp16=False, pair=False, serial_chains=None):
     """``imcoco_motion_correction`` for a batch (BASELINE config 3: B slices resident on one GPU):
     ``kspaces [B, H, W] c64`` and one ``masks [nM_i, H, W]`` per slice.  Slices with the same number of
     movement groups share one ``immoco_solver_solve_batch`` call (parameters, Adam state and outputs live in
@@ -383,7 +383,8 @@ def imcoco_motion_correction_batch(kspaces, masks_list, iters=200, learning_rate
             raise L.ImmocoError(f"masks[{i}] shape {tuple(m.shape)} does not match kspaces {(H, W)}")
         by_nm.setdefault(int(m.shape[0]), []).append(i)
     for nM, idx in sorted(by_nm.items()):
-        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16, lanes, mlp_fp16=mlp_fp16, batch_pair=pair)
+        solver = get_solver(dev, H, W, nM, use_graph, False, 0, 0, table_fp16, lanes, mlp_fp16=mlp_fp16,
+                            serial_chains=serial_chains, batch_pair=pair)
         Bg = len(idx)
         k = kspaces[idx].to(torch.complex64).contiguous()
         kin = torch.empty_like(k)
