@@ -183,7 +183,8 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   }
   };
   auto push_image_fwd = [&] {
-  if (s->pruned && split_image_bwd(s->cfg) && backward && nM > 0)   // (= early_img below) the warp backward's dL/dimage share
+  static const bool early_env0 = [] { const char* e = immoco_diag_env("IMMOCO_EARLY_IMG"); return e && atoi(e) != 0; }();
+  if (early_env0 && s->pruned && split_image_bwd(s->cfg) && backward && nM > 0)   // (= early_img below) the warp backward's dL/dimage share
     st.push_back({"zero_dimage_warp", [=](hipStream_t q) {
                     IMMOCO_CHECK_HIP(hipMemsetAsync(s->dimage_w, 0, (size_t)P * 8, q));
                     return IMMOCO_OK;
@@ -218,7 +219,13 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
   // beside the warp backward instead, dL/dimage = [sign*adj0 + lambda dGE] + [the warp backward's share] is summed where
   // the MLP backward kernels load it (two planar addends), and the warp's accumulation buffer is cleared at the start
   // of the next image forward.
-  const bool early_img = pruned && split_image_bwd(s->cfg) && backward && nM > 0;
+  // MEASURED (800 iterations, two runs each): early 1.2110 / 1.2114 ms per iteration in fp32 and 0.9797 / 0.9778 with fp16 MLPs;
+  // late (the image branch forks after the motion MLP backward, its three small kernels and the sum kernel in the encode
+  // backward's shadow) 1.1952 and 0.9562 - the d enc kernel beside the motion MLP backward costs the critical chain more
+  // than the small kernels' queueing costs the image chain, which has 200 us of slack.  Late is the default; the early
+  // variant stays behind IMMOCO_EARLY_IMG=1 in the diagnostics build.
+  static const bool early_env = [] { const char* e = immoco_diag_env("IMMOCO_EARLY_IMG"); return e && atoi(e) != 0; }();
+  const bool early_img = early_env && pruned && split_image_bwd(s->cfg) && backward && nM > 0;
   float* zt0 = s->fft_t + 2 * P;   // pruned path: the adjoint seed of the unwarped image (its own columns only), [W][H]
   if (pruned) {
     // warp + row DFT of every motion image's own columns -> Z; ONE column transform; the select is implicit
@@ -263,7 +270,10 @@ std::vector<Step> build_steps(immoco_solver* s, const Bind& b, bool backward) {
     const char* e = immoco_diag_env("IMMOCO_FORK");
     return !e ? -1 : (strcmp(e, "early") == 0 ? 1 : 0);
   }();
-  const bool fork_early = fork_env >= 0 ? fork_env == 1 : false;   // measured slower in every mode
+  // Round 4, split wide backward + pruned path (800 iterations): fp32 late 1.1854 / early 1.2126 ms per iteration; fp16 MLPs
+  // late 0.9552 / early 0.9472 - with fp16 MLPs the motion MLP backward is short (69 us) and VALU-bound, and the image
+  // chain's MFMA kernels fit beside it.
+  const bool fork_early = fork_env >= 0 ? fork_env == 1 : (s->cfg.mlp_fp16 == 1 && split_image_bwd(s->cfg) && s->pruned);
   if (nM > 0) {
     st.push_back({"motion_warp_bwd", [=](hipStream_t q) {
                     if (pruned)   // adjoint row DFT on the fly; dL/dimage share into dimage_w (summed by the late grad init)
