@@ -27,7 +27,128 @@ cg = M.masks_to_col_group(masks)
 ge_hip = pkg.GradientEntropyLoss()
 
 
+import ctypes as C
+from miccai24_immoco_amd import _lib as L
+from miccai24_immoco_amd import tcnn as T
+
+
+class _EncHIP(torch.autograd.Function):
+    """hash-grid encode forward (lattice kernel) and backward (transposed-index plan) of the package, alone"""
+    @staticmethod
+    def forward(ctx, tab, mod):
+        n = mod.n
+        enc = torch.empty((16, n, 2), device=dev, dtype=torch.float32)
+        pl = mod.plan
+        L.check(L.lib().immoco_hashgrid_fwd_lattice(C.byref(mod.gcfg), pl.nM, pl.H, pl.W, L.ptr(pl.axes[0]), L.ptr(pl.axes[1]),
+                                                    L.ptr(pl.axes[2]), L.ptr(tab), L.ptr(enc), 2, 2 * n, L.stream_ptr()), "fwd")
+        ctx.mod = mod
+        return enc.permute(1, 0, 2).reshape(n, 32)
+
+    @staticmethod
+    def backward(ctx, g):
+        mod = ctx.mod
+        n = mod.n
+        denc = g.reshape(n, 16, 2).permute(1, 0, 2).contiguous()
+        dtab = torch.zeros(mod.n_entries * 2, device=dev, dtype=torch.float32)
+        L.check(L.lib().immoco_grid_plan_bwd(mod.plan.handle, L.ptr(denc), L.ptr(dtab), L.stream_ptr()), "bwd")
+        return dtab, None
+
+
+class _MlpHIP(torch.autograd.Function):
+    """the package's MLP forward / backward kernels (exact fp32, matrix cores) on a point-major encoding"""
+    @staticmethod
+    def forward(ctx, enc, w1, w2, mod):
+        n = enc.shape[0]
+        enc = enc.contiguous()
+        out = torch.empty((n, 2), device=dev, dtype=torch.float32)
+        L.check(L.lib().immoco_mlp_fwd(C.byref(mod.mcfg), L.ptr(enc), 32, 2, n, L.ptr(w1.contiguous()), L.ptr(w2.contiguous()), L.ptr(out), L.stream_ptr()), "mlp_fwd")
+        ctx.mod = mod
+        ctx.save_for_backward(enc, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc, w1, w2 = ctx.saved_tensors
+        mod = ctx.mod
+        n = enc.shape[0]
+        denc = torch.empty_like(enc)
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        L.check(L.lib().immoco_mlp_bwd(C.byref(mod.mcfg), L.ptr(enc), 32, 2, n, L.ptr(w1.contiguous()), L.ptr(w2.contiguous()),
+                                       L.ptr(dout.contiguous()), L.ptr(denc), L.ptr(dw1), L.ptr(dw2), L.stream_ptr()), "mlp_bwd")
+        return denc, dw1, dw2, None
+
+
+class _MlpMixed(torch.autograd.Function):
+    """fwd_hip: the forward through the package's kernel and the backward through torch's formulas (or the other way round)"""
+    @staticmethod
+    def forward(ctx, enc, w1, w2, mod, fwd_hip):
+        n = enc.shape[0]
+        enc = enc.contiguous()
+        act = torch.relu if mod.o.mlp.activation == "relu" else torch.tanh
+        if fwd_hip:
+            out = torch.empty((n, 2), device=dev, dtype=torch.float32)
+            L.check(L.lib().immoco_mlp_fwd(C.byref(mod.mcfg), L.ptr(enc), 32, 2, n, L.ptr(w1.contiguous()), L.ptr(w2.contiguous()), L.ptr(out), L.stream_ptr()), "mlp_fwd")
+        else:
+            out = (act(enc @ w1.t()) @ w2.t())[:, :2].contiguous()
+        ctx.mod, ctx.fwd_hip = mod, fwd_hip
+        ctx.save_for_backward(enc, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc, w1, w2 = ctx.saved_tensors
+        mod = ctx.mod
+        n = enc.shape[0]
+        if ctx.fwd_hip:      # torch backward
+            pre = enc @ w1.t()
+            relu = mod.o.mlp.activation == "relu"
+            h = torch.relu(pre) if relu else torch.tanh(pre)
+            dpad = torch.zeros((n, w2.shape[0]), device=dev)
+            dpad[:, :2] = dout
+            dw2 = dpad.t() @ h
+            dh = dpad @ w2
+            dpre = dh * ((h > 0).float() if relu else (1 - h * h))
+            return dpre @ w1, dpre.t() @ enc, dw2, None, None
+        denc = torch.empty_like(enc)
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        L.check(L.lib().immoco_mlp_bwd(C.byref(mod.mcfg), L.ptr(enc), 32, 2, n, L.ptr(w1.contiguous()), L.ptr(w2.contiguous()),
+                                       L.ptr(dout.contiguous()), L.ptr(denc), L.ptr(dw1), L.ptr(dw2), L.stream_ptr()), "mlp_bwd")
+        return denc, dw1, dw2, None, None
+
+
+class HybridINR(torch.nn.Module):
+    """enc = "hip" | "torch", mlp = "hip" | "torch": one INR assembled from the package's kernels and the device oracle's
+    torch expressions, same parameters / initialisation as both."""
+    def __init__(self, dims, net_cfg, x, enc, mlp):
+        super().__init__()
+        self.o = orc.OracleINR(dims, 2, orc.encoding_config, net_cfg, seed=1337, device=dev)
+        self.params = self.o.params
+        self.enc_kind, self.mlp_kind, self.x = enc, mlp, x
+        self.n = x.shape[0]
+        self.gcfg = L.grid_cfg(dims, pkg.encoding_config)
+        self.mcfg = L.mlp_cfg(32, 2, net_cfg)
+        self.n_entries = self.o.geo.n_entries
+        lat = T._detect_lattice(x)
+        self.plan = T._GridPlan(self.gcfg, *lat)
+
+    def forward(self, x):
+        w1, w2, tab = self.o.split()
+        enc = _EncHIP.apply(tab.reshape(-1), self) if self.enc_kind == "hip" else self.o.plan_for(x).encode(tab)
+        if self.mlp_kind == "hip":
+            return _MlpHIP.apply(enc, w1, w2, self)
+        if self.mlp_kind in ("hipfwd", "hipbwd"):
+            return _MlpMixed.apply(enc, w1, w2, self, self.mlp_kind == "hipfwd")
+        pre = enc @ w1.t()
+        h = torch.relu(pre) if self.o.mlp.activation == "relu" else torch.tanh(pre)
+        return (h @ w2.t())[:, :2]
+
+
 def make_inrs():
+    if cfg["inr"].startswith("hyb"):      # inr=hyb:<image enc><image mlp><motion enc><motion mlp>, each h | t
+        k = cfg["inr"].split(":")[1]
+        m = {"h": "hip", "t": "torch", "f": "hipfwd", "b": "hipbwd"}
+        return (HybridINR(2, orc.network_config, identy.view(-1, 2), m[k[0]], m[k[1]]),
+                HybridINR(3, orc.mot_network_config, grid_in, m[k[2]], m[k[3]]))
     if cfg["inr"] in ("hip_img", "hip_mot"):      # one INR from the package, the other from the device oracle
         lp = cfg["plans"] == "1"
         hi = pkg.NetworkWithInputEncoding(2, 2, pkg.encoding_config, pkg.network_config, seed=1337, device=dev, lattice_plans=lp)
