@@ -447,9 +447,14 @@ class OracleINR(torch.nn.Module):
     first forward (the reference always passes the same grid)."""
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False,
-                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True, device=None, tanh="torch"):
+                 backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True, device=None, tanh="torch",
+                 mlp_f64=False):
         super().__init__()
         self.tanh = tanh_alt if tanh == "alt" else torch.tanh
+        # mlp_f64: the three matrix products of the MLP and their autograd transposes accumulate in float64 (operands are the
+        # fp32 values, results are rounded to fp32 once): the MLP "without GEMM rounding noise" of the sensitivity
+        # experiment of DESIGN.md 2.4 (the HIP kernels' fused-multiply-add chains are closer to this than to a blocked fp32 GEMM)
+        self.mlp_f64 = mlp_f64
         # device != cpu: the DEVICE ORACLE (ATen kernels only; HashGridPlan.encode_device) - the fast sampler
         # of the statistical parity fixtures (tools/device_oracle_sampler.py); validated against the CPU oracle
         # by tests/test_gpu_ops.py::test_device_oracle_vs_cpu_oracle_teacher_forced
@@ -513,9 +518,14 @@ class OracleINR(torch.nn.Module):
         if self.mlp_fp16:
             out = _MLPHalf.apply(enc, w1, w2, self.mlp.activation, self.loss_scale, self.denc_fp16)
         else:
-            pre = enc @ w1.t()
-            h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)
-            out = h @ w2.t()
+            if self.mlp_f64:
+                pre = (enc.double() @ w1.double().t()).float()
+                h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)
+                out = (h.double() @ w2.double().t()).float()
+            else:
+                pre = enc @ w1.t()
+                h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)
+                out = h @ w2.t()
         if perm is not None:
             out = torch.empty_like(out).index_copy(0, perm, out)
         return out[:, : self.n_output_dims]

@@ -1551,20 +1551,6 @@ def test_config2_distribution_vs_oracle_draws(env, golden):
     assert se <= 0.6 and abs(delta) <= 3.0 * se + 0.05, (delta, se, h_med, o_med)
 
 
-def _blowups(loss, a, b, thr=1.5):
-    """Loss blow-up events in [a, b): loss above thr x the median of the previous 20 iterations (40 iterations of
-    dead time after an event) -> [(iteration, ratio)]."""
-    ev, t = [], a
-    while t < b:
-        med = float(np.median(loss[t - 20:t]))
-        if loss[t] > thr * med:
-            ev.append((t, float(loss[t] / med)))
-            t += 40
-        else:
-            t += 1
-    return ev
-
-
 _CPU_SLICES = {}
 
 
@@ -1616,7 +1602,7 @@ def _cell_sample(env, golden, cell, mode):
         grid = list(range(179, 200))
         o_stat = np.median(g[key][:, 179:200].astype(np.float64), axis=1)
         o_l0 = float(g[f"s{sl}_it200_loss"][0, 0])
-        n_runs, sched = (40 if mode == "f32" else 32), 200
+        n_runs, sched = ((40 if mode == "f32" else 32) if sl in (1, 4, 9) else 24), 200
     assert len(o_stat) >= 48, len(o_stat)
     h = []
     for _ in range(n_runs):
@@ -1674,20 +1660,26 @@ def test_cells_vs_device_oracle_draws(env, golden, cell, mode):
 
 @pytest.mark.parametrize("mode", ["f32", "f16mlp"])
 def test_reference_setting_mean_over_slices_vs_device_oracle(env, golden, mode):
-    """The reference's operating point (iters=200, seed 1337) averaged over the three slices 1, 4, 9: the per-slice offsets
-    have either sign (+0.6, -1.45, +0.4 dB in fp32), their mean is zero within 3 standard errors (measured -0.15 +- 0.15 fp32,
-    -0.06 +- 0.15 f16mlp), and no slice is off by more than 2.5 dB (a gross-regression guard, not a parity statement)."""
+    """The reference's operating point (iters=200, seed 1337) averaged over slices: the per-slice offsets have either sign
+    (+0.6, -1.45, +0.4 dB on the pre-registered slices 1, 4, 9 in fp32), their mean is zero within 3 standard errors (measured
+    -0.15 +- 0.15 fp32, -0.06 +- 0.15 f16mlp), and no slice is off by more than 2.5 dB (a gross-regression guard, not a parity
+    statement).  In fp32 the mean also runs over slices 2, 6, 7 (48 device-oracle draws each, drawn AFTER the first comparison
+    to see whether the offsets average out over more slices; 24 HIP runs each here) when the fixture holds them."""
     from miccai24_immoco_amd.utils.sampling import delta_with_se
+    g = golden("c2_device_oracle_draws")
+    slices = [1, 4, 9] + ([sl for sl in (2, 6, 7) if f"s{sl}_it200_psnr" in g] if mode == "f32" else [])
     ds, ses = [], []
-    for sl in (1, 4, 9):
+    for sl in slices:
         h, o = _cell_sample(env, golden, f"it200_s{sl}", mode)
         d, se, _ = delta_with_se(h, o)
         ds.append(d)
         ses.append(se)
         assert abs(d) <= 2.5, (sl, mode, d, se)
-    mean, se_mean = float(np.mean(ds)), float(np.sqrt(np.sum(np.square(ses))) / 3.0)
-    print(f"it200, {mode}: per-slice deltas {np.round(ds, 3).tolist()} +- {np.round(ses, 3).tolist()}; mean over slices {mean:.3f} +- {se_mean:.3f}")
-    assert abs(mean) <= 3.0 * se_mean, (ds, ses)
+    for n in sorted({3, len(slices)}):
+        mean, se_mean = float(np.mean(ds[:n])), float(np.sqrt(np.sum(np.square(ses[:n]))) / n)
+        print(f"it200, {mode}: slices {slices[:n]} per-slice deltas {np.round(ds[:n], 3).tolist()} +- {np.round(ses[:n], 3).tolist()}; "
+              f"mean over slices {mean:.3f} +- {se_mean:.3f}")
+        assert abs(mean) <= 3.0 * se_mean, (slices[:n], ds, ses)
 
 
 def test_config2_plateau_by_initialisation_vs_oracle_draws(env, golden):

@@ -1,4 +1,4 @@
-# round-4 evidence, part $1 (a | b): every GPU step must succeed before the next one starts.
+# round-4 evidence, part $1 (a | b | c): every GPU step must succeed before the next one starts.
 set -e -o pipefail
 mkdir -p gpurun_out/final
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -23,6 +23,14 @@ if [ "$1" = "a" ]; then
     rm -rf gpurun_out/tl/$mode
   done
   ls gpurun_out/final/kt_default/*/
+elif [ "$1" = "c" ]; then   # the two pair lines alone, then the HIP side of the added 200-iteration cells (slices 2, 6, 7)
+  python3 bench.py --workload c3 --batch 64 --steps 1 --warmup 0 --no-cpu-baseline --pair > gpurun_out/final/bench_c3_pair.json 2> gpurun_out/final/bench_c3_pair.err
+  python3 bench.py --workload c3 --batch 64 --steps 1 --warmup 0 --no-cpu-baseline --pair --precision f16mlp > gpurun_out/final/bench_c3_pair_f16mlp.json 2> gpurun_out/final/bench_c3_pair_f16mlp.err
+  for f in c3_pair c3_pair_f16mlp; do tail -n 1 gpurun_out/final/bench_$f.json | cut -c1-200; done
+  mkdir -p gpurun_out/cells2
+  for sl in 2 6 7; do for pr in f32 f16mlp; do
+    python3 tools/hip_cell_sampler.py --cell it200 --slice $sl --runs 64 --precision $pr --out gpurun_out/cells2/it200_s${sl}_$pr.npz | tee -a gpurun_out/cells2/summary.txt
+  done; done
 else
   python3 bench.py --workload c3 --batch 64 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_c3_serial.json 2> gpurun_out/final/bench_c3_serial.err
   python3 bench.py --workload c3 --batch 64 --steps 1 --warmup 0 --no-cpu-baseline --pair > gpurun_out/final/bench_c3_pair.json 2> gpurun_out/final/bench_c3_pair.err

@@ -3,9 +3,11 @@
 oracle's restatement evaluated by ATen on the GPU, fp32, nondeterministic atomics; every draw from the reference's one
 initialisation, seed 1337):
 
-    python tools/make_device_fixtures.py gpurun_out/dorc
+    python tools/make_device_fixtures.py gpurun_out/dorc [gpurun_out/dorc2 ...]
 
-  s{1,4,9}_it200_psnr / _loss   [draws, 200]   the reference script's iters=200 (src/test/test_immoco.py:65-72), every iteration
+  s{1,4,9,2,6,7}_it200_psnr / _loss  [draws, 200]  the reference script's iters=200 (src/test/test_immoco.py:65-72), every
+                                               iteration (1 / 4 / 9: the pre-registered cells, 64 draws; 2 / 6 / 7: added after the
+                                               first comparison to average the per-slice offsets over more slices, 48 draws)
   s1_plateau_psnr               [draws, 201]   slice 1, the metric's 3000-iteration solve, iterations 0, 5, ..., 1000
   s1_plateau_loss               [draws, 1001]  every iteration
   *_f16 variants                               the same cells with OracleINR(mlp_fp16=True) where drawn
@@ -17,12 +19,12 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1]
+srcs = sys.argv[1:]
 out = {}
 
 
 def merge(pattern):
-    recs = [np.load(f) for f in sorted(glob.glob(os.path.join(src, pattern)))]
+    recs = [np.load(f) for src in srcs for f in sorted(glob.glob(os.path.join(src, pattern)))]
     recs = [r for r in recs if r["psnr"].shape[0] > 0]
     if not recs:
         return None
@@ -35,7 +37,7 @@ def merge(pattern):
                 kspace_abs_sum=float(r0["kspace_abs_sum"]), n_groups=int(r0["n_groups"]))
 
 
-for sl in (1, 4, 9):
+for sl in (1, 4, 9, 2, 6, 7):
     for tag, suffix in (("f32", ""), ("f16", "_f16")):
         m = merge(f"s{sl}_200_{tag}*.npz")
         if m is None:
