@@ -448,13 +448,17 @@ class OracleINR(torch.nn.Module):
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337, table_fp16=False,
                  backend="c", bwd_order=0, mlp_fp16=False, loss_scale=128.0, denc_fp16=True, device=None, tanh="torch",
-                 mlp_f64=False):
+                 mlp_f64=False, mlp_splitk=0):
         super().__init__()
         self.tanh = tanh_alt if tanh == "alt" else torch.tanh
         # mlp_f64: the three matrix products of the MLP and their autograd transposes accumulate in float64 (operands are the
         # fp32 values, results are rounded to fp32 once): the MLP "without GEMM rounding noise" of the sensitivity
         # experiment of DESIGN.md 2.4 (the HIP kernels' fused-multiply-add chains are closer to this than to a blocked fp32 GEMM)
         self.mlp_f64 = mlp_f64
+        # mlp_splitk = c > 1: every matrix product of the MLP (and, through autograd, of its backward) is evaluated as the sum
+        # of c products over interleaved slices k = j mod c of its inner dimension - another equally valid fp32 evaluation
+        # order of the same sums (what a different GEMM tiling does); sensitivity experiment of DESIGN.md 2.4
+        self.mlp_splitk = int(mlp_splitk)
         # device != cpu: the DEVICE ORACLE (ATen kernels only; HashGridPlan.encode_device) - the fast sampler
         # of the statistical parity fixtures (tools/device_oracle_sampler.py); validated against the CPU oracle
         # by tests/test_gpu_ops.py::test_device_oracle_vs_cpu_oracle_teacher_forced
@@ -522,6 +526,11 @@ class OracleINR(torch.nn.Module):
                 pre = (enc.double() @ w1.double().t()).float()
                 h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)
                 out = (h.double() @ w2.double().t()).float()
+            elif self.mlp_splitk > 1:
+                c = self.mlp_splitk
+                pre = sum(enc[:, j::c] @ w1[:, j::c].t() for j in range(c))
+                h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)
+                out = sum(h[:, j::c] @ w2[:, j::c].t() for j in range(c))
             else:
                 pre = enc @ w1.t()
                 h = torch.relu(pre) if self.mlp.activation == "relu" else self.tanh(pre)

@@ -53,6 +53,7 @@ _MODELS = {}
 
 TANH = "torch"
 MLP_F64 = False
+MLP_SPLITK = 0
 
 
 def fresh_model(masks, seed, mlp_fp16, dev):
@@ -60,7 +61,7 @@ def fresh_model(masks, seed, mlp_fp16, dev):
     are built once, every draw restarts from the initial parameters."""
     key = (tuple(masks.shape), seed, bool(mlp_fp16))
     if key not in _MODELS:
-        kw = dict(seed=seed, device=dev, mlp_fp16=mlp_fp16, tanh=TANH, mlp_f64=MLP_F64)
+        kw = dict(seed=seed, device=dev, mlp_fp16=mlp_fp16, tanh=TANH, mlp_f64=MLP_F64, mlp_splitk=MLP_SPLITK)
         m = orc.OracleIMMoCo(masks, image_inr=orc.OracleINR(2, 2, orc.encoding_config, orc.network_config, **kw),
                              motion_inr=orc.OracleINR(3, 2, orc.encoding_config, orc.mot_network_config, **kw))
         _MODELS[key] = (m, m.image_inr.params.detach().clone(), m.motion_inr.params.detach().clone())
@@ -102,13 +103,15 @@ def main():
     ap.add_argument("--seed", type=int, default=1337)
     ap.add_argument("--mlp-fp16", action="store_true")
     ap.add_argument("--mlp-f64", action="store_true", help="MLP matrix products accumulated in float64 (sensitivity experiment)")
+    ap.add_argument("--mlp-splitk", type=int, default=0,
+                    help="MLP products summed over c interleaved slices of the inner dimension (sensitivity experiment)")
     ap.add_argument("--tanh", choices=["torch", "alt"], default="torch",
                     help="alt: an equally valid fp32 tanh formula (sensitivity experiment, DESIGN.md 2.4)")
     ap.add_argument("--budget-s", type=float, default=1e9, help="start no new draw after this many seconds")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    global TANH, MLP_F64
-    TANH, MLP_F64 = a.tanh, a.mlp_f64
+    global TANH, MLP_F64, MLP_SPLITK
+    TANH, MLP_F64, MLP_SPLITK = a.tanh, a.mlp_f64, a.mlp_splitk
     run = a.run or a.sched
     dev = torch.device("cuda", 0)
     k, lines, gt = slice_input(a.slice)

@@ -11,6 +11,7 @@ initialisation, seed 1337):
   s1_plateau_psnr               [draws, 201]   slice 1, the metric's 3000-iteration solve, iterations 0, 5, ..., 1000
   s1_plateau_loss               [draws, 1001]  every iteration
   *_f16 variants                               the same cells with OracleINR(mlp_fp16=True) where drawn
+  s{2,4}_it200_psnr_sk{2,4,8} / _loss_sk*  [32, 200]  the oracle with mlp_splitk = 2 / 4 / 8 (tests/test_oracle_family.py)
 """
 import glob
 import os
@@ -49,6 +50,18 @@ for sl in (1, 4, 9, 2, 6, 7):
         out[f"s{sl}_n_groups"] = np.int32(m["n_groups"])
         st = np.median(m["psnr"][:, 179:200], axis=1)
         print(f"slice {sl} it200 {tag}: {len(st)} draws, median-of-last-21 PSNR mean {st.mean():.3f} sd {st.std(ddof=1):.3f} "
+              f"se {st.std(ddof=1) / np.sqrt(len(st)):.3f}")
+# the oracle FAMILY: the same restatement with its MLP products summed over c interleaved slices of the inner dimension
+# (OracleINR(mlp_splitk=c): another equally valid fp32 evaluation order), 32 draws each
+for sl in (2, 4):
+    for c in (2, 4, 8):
+        m = merge(f"s{sl}_200_sk{c}.npz")
+        if m is None:
+            continue
+        out[f"s{sl}_it200_psnr_sk{c}"] = m["psnr"].astype(np.float32)
+        out[f"s{sl}_it200_loss_sk{c}"] = m["loss"].astype(np.float32)
+        st = np.median(m["psnr"][:, 179:200], axis=1)
+        print(f"slice {sl} it200 split-K {c}: {len(st)} draws, median-of-last-21 PSNR mean {st.mean():.3f} sd {st.std(ddof=1):.3f} "
               f"se {st.std(ddof=1) / np.sqrt(len(st)):.3f}")
 for tag, suffix in (("f32", ""), ("f16", "_f16")):
     m = merge(f"s1_plateau_{tag}*.npz")
