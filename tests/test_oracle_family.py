@@ -70,14 +70,18 @@ def test_oracle_family_level_moves_with_the_summation_order(sl):
     mp, sp = _mean_se(pooled)
     shift, se = mp - mb, float(np.hypot(sp, sb))
     print(f"  pooled split-K {mp:.3f} +- {sp:.3f}; shift {shift:+.3f} +- {se:.3f} ({shift / se:+.1f} s.e.)")
-    # the perturbation itself is tiny: identical start, the ensembles' mean log-loss agrees to 1e-3 through iteration 5
+    # the perturbation itself is tiny: identical start, the ensembles' mean log-loss agrees to 1e-4 through iteration 3
+    # (by iteration 5 the members are 5e-4 ... 3e-3 apart - up to 15 standard errors - and stay so through iteration 40: on
+    # slice 4 the members that are > 1.5e-3 above the plain oracle there end 1.5 dB below it, the one at 5e-4 ends level)
     lo = np.log(g[f"s{sl}_it200_loss"].astype(np.float64))
     for c in (2, 4, 8):
         lf = np.log(g[f"s{sl}_it200_loss_sk{c}"].astype(np.float64))
         assert abs(lf[:, 0].mean() - lo[:, 0].mean()) <= 1e-7
-        assert np.abs(lf[:, :6].mean(axis=0) - lo[:, :6].mean(axis=0)).max() <= 1e-3, c
+        assert np.abs(lf[:, :4].mean(axis=0) - lo[:, :4].mean(axis=0)).max() <= 1e-4, c
     # ... the spread of the plain oracle's draws at iteration 2 is the order of its atomics alone
     assert lo[:, 2].std(ddof=1) <= 1e-7
-    # ... and the 200-iteration level is not common to the family (measured: slice 2 -1.39 +- 0.44)
-    if sl == 2:
-        assert abs(shift) >= 2.0 * se, (shift, se)
+    # ... and the 200-iteration level is not common to the family (measured: slice 2 pooled -1.40 +- 0.44; slice 4 members
+    # -1.48 +- 0.42, +0.26 +- 0.36, -1.48 +- 0.55, pooled -0.86 +- 0.33)
+    assert abs(shift) >= 2.0 * se, (shift, se)
+    means = [m for m, _ in map(_mean_se, [base] + fam)]
+    assert max(means) - min(means) >= 1.0, means
