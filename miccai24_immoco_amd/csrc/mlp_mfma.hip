@@ -38,24 +38,36 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, const f32x16& c) {
 // row index of D register g for lane half h
 __device__ __forceinline__ int drow(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
-// tanh in thirteen instructions: 1 - 2/(exp(2|x|) + 1) on v_exp_f32 / v_rcp_f32 for |x| >= 0.5 (absolute error ~1e-7, relative
-// <= 3e-7 there) and x (1 + u (c0 + c1 u + c2 u^2 + c3 u^3)), u = x^2, below 0.5 (a least-squares Chebyshev-node fit of
-// (tanh(x)/x - 1)/u on [0, 0.25]: relative error <= 1e-7, rms 3e-8 - the rounding floor).
-// Keeping the RELATIVE accuracy for small arguments matters twice.  The motion field starts at ~1e-3: an absolute-only tanh
-// (six instructions) shifted the loss of iteration 5 by 1.3e-3 against the oracle.  And the exp form loses relative accuracy
-// below ~0.3 (1 - 2/(e+1) cancels: rms 8e-7 in [0.04, 0.1), 2.6e-7 in [0.1, 0.3), which is where the motion net's hidden
-// units live): the weight gradients of a nearly converged motion net are residuals of cancelling sums over 1 M points, and
-// that 1e-6 came out as 1.5e-4 ... 4.6e-4 (rel. L2) in the motion gradient against the oracle, where the VALU kernels with
-// libm tanhf had 3e-6 (round 4: tools/diag_tf_slice.py, test_teacher_forced_state_c2_shape).  Rounds 1-3 used x - x^3/3
-// below 0.04 and the exp form above (ten instructions); a 17-instruction series form was 40 % of the forward VALU work.
+// tanh in ten instructions: 1 - 2/(exp(2|x|) + 1) on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7,
+// i.e. relative <= 3e-6 for |x| >= 0.04) and x - x^3/3 below 0.04 (relative error < 4e-7).
+// Keeping the RELATIVE accuracy for tiny arguments matters: the motion field starts at ~1e-3 and
+// an absolute-only tanh (six instructions) shifted the loss of iteration 5 by 1.3e-3 against the
+// oracle (2e-4 with this form); a 17-instruction series form was 40 % of the forward VALU work.
+//
+// Round 4, built and NOT shipped (-DIMMOCO_DIAG_POLY_TANH; `make diag EXTRA=-DIMMOCO_DIAG_POLY_TANH`): the exp form loses
+// relative accuracy below ~0.3 (1 - 2/(e+1) cancels: rms 8e-7 in [0.04, 0.1), 2.6e-7 in [0.1, 0.3) - where the motion
+// net's hidden units live), and the weight gradients of a nearly converged motion net are residuals of cancelling sums over
+// 1 M points: on some late states that 1e-6 comes out as 1.5e-4 ... 4.6e-4 (rel. L2) in the motion gradient against the
+// oracle where the VALU kernels with libm tanhf have 3e-6 (tools/diag_tf_slice.py).  The variant below - x (1 + u (c0 + c1 u
+// + c2 u^2 + c3 u^3)), u = x^2, for |x| < 0.5, a Chebyshev-node least-squares fit, relative error <= 1e-7 (rms 3e-8, the
+// rounding floor); thirteen instructions, the same 0.2784 slices/s - makes HIP's single steps coincide with the DEVICE
+// oracle's: both then differ from the CPU oracle by the same 3.59e-5 / 3.63e-5 (K = 5, 320x320) and 1.350e-5 / 1.354e-5
+// (K = 60, 96x96) in the motion gradient, and 78 of 9.45 M Adam updates move by more than 1e-3 lr against the CPU oracle
+// (gpurun_out -> DESIGN.md 2.5).  Every ensemble of DESIGN.md 2.4 was drawn with the ten-instruction form, so that is what
+// ships; switching needs the cells redrawn.
 __device__ __forceinline__ float tanh_fast(float x) {
   const float ax = fabsf(x);
   const float e = __builtin_amdgcn_exp2f(ax * 2.885390082f);  // exp(2|x|) = 2^(2|x| log2 e)
   const float big = fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+#ifdef IMMOCO_DIAG_POLY_TANH
   const float u = ax * ax;
   const float p = fmaf(fmaf(fmaf(0.017999219f, u, -0.053391054f), u, 0.13330513f), u, -0.3333331f);
   const float small = fmaf(ax * u, p, ax);
   return copysignf(ax < 0.5f ? small : big, x);
+#else
+  const float small = ax * fmaf(ax * ax, -0.33333334f, 1.f);
+  return copysignf(ax < 0.04f ? small : big, x);
+#endif
 }
 
 template <int ACT>
