@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(const float* __restri
 // d enc into a zeroed buffer): 0.155 ms alone instead of 0.148, still 0.47 ms beside the encode backward (whose four
 // 33 KB workgroups per CU leave no 71 KB hole), and the 13 MB memset costs the image chain another 0.06 ms:
 // graph iteration 1.353 instead of 1.346 ms.  Not kept.
-template <int HID, int ACT>
+// RAW (diagnostics build only, IMMOCO_MLP_RAWLOAD=1): the next tile's loads carry no arithmetic (see load_raw)
+template <int HID, int ACT, bool RAW = false>
 __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(const float* in /* may alias din */, int64_t ps, int64_t ls,
                                                            int64_t n, const float* __restrict__ w1,
                                                            const float* __restrict__ w2,
@@ -237,10 +238,22 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
   float nx[16];
   float2 nx_d = make_float2(0.f, 0.f);
+  // (load_enc_b multiplies every value by the tail mask, so the compiler waits for these "prefetch" loads on the spot -
+  // s_waitcnt vmcnt(16) ... vmcnt(0) directly behind them in the ISA.  RAW: no arithmetic here; only dout needs the mask -
+  // a point beyond n then has dpre = 0 and its clamped, finite encoding contributes nothing - applied one tile later.)
+  float mnx = 1.f;
   auto load_raw = [&](int64_t tt) {
     const int64_t q = tt * 32 + r;
     const int64_t qc = q < n ? q : n - 1;
     const float mq = q < n ? 1.f : 0.f;
+    if (RAW) {
+      mnx = mq;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) nx[s] = in[qc * ps + (int64_t)s * ls + h];
+      if (dout_plane) nx_d = make_float2(dout[qc], dout[dout_plane + qc]);
+      else nx_d = *reinterpret_cast<const float2*>(dout + qc * 2);
+      return;
+    }
     load_enc_b(in, ps, ls, q, n, h, nx);
     if (dout_plane) {  // wave-uniform
       nx_d = make_float2(dout[qc] * mq, dout[dout_plane + qc] * mq);
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
     float eb[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) eb[s] = nx[s];
-    const float2 d = nx_d;
+    const float2 d = RAW ? make_float2(nx_d.x * mnx, nx_d.y * mnx) : nx_d;
     if (t + n_waves < n_tiles) load_raw(t + n_waves);
     // ---- stage dout and the enc tile (rows = feature k = 2s + h, cols = point) in LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier readers (previous tile) are done
@@ -413,6 +426,293 @@ __global__ __launch_bounds__(256, HID == 64 ? 2 : 1) void mlp_bwd_mfma_kernel(co
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENT (diagnostics library only: IMMOCO_MLP_BWD64=pipe | pipe_partials | pipe_<ablation>; written and measured with the
+// last GPU minutes of round 4, profiles/r04_narrow_mlp_bwd_ablations.txt; the shipped library does not contain it): the narrow
+// backward with its matrix-core chains and its VALU work INTERLEAVED inside the wave.
+// Why it was tried: per 32-point tile the kernel above issues 96 v_mfma_f32_32x32x2_f32 (6144 cycles of the SIMD's matrix pipe:
+// 0.080 ms for 32 000 tiles on 1024 SIMDs at 2.4 GHz) and ~570 VALU instructions incl. 64 quarter-rate ones, and takes 0.176 ms;
+// its ISA is strictly phase after phase - 16 dependent MFMAs, `s_nop 14`, the tanh block, 16 MFMAs, the transpose, 16 MFMAs.
+// Here the two hidden tiles are software-pipelined: while the matrix pipe runs a chain of one tile the VALU does the activation
+// work of the other,
+//     pre0 | pre1 + V(pre0)a | d enc(dp0) + V(pre0)b | dW1_0 + V(pre1)a | d enc(dp1) + V(pre1)b | dW1_1 + next loads, stores
+// (V(.)a / b = the two halves of a hidden tile's activation work) with `sched_group_barrier` pinning "1 MFMA, then 7 VALU" in the
+// four mixed stages (`hipcc -S`: 242 registers, no scratch, every MFMA of those stages followed by ~7 VALU instructions).
+// Arithmetic, operand order and the order of every accumulation are those of mlp_bwd_mfma_kernel<64, ACT>.
+// MEASURED: correct (3e-7 against float64) and NOT faster - 0.197 against 0.191 ms in the same harness.  The kernel is not
+// issue-bound: with ReLU instead of tanh the shipped kernel takes the same time; without any MFMA this one takes 0.100 ms,
+// without MFMA and activation work 0.097, i.e. the kernel is the SUM of its matrix-core time (0.096 ms, the full rate) and
+// of a memory / LDS skeleton that is 2.3x slower than a plain copy of the same bytes, and the two do not overlap.  The
+// partial-sum flush (ABL = 12 below: no atomics, deterministic, more accurate) saves 7 us; raw prefetch loads 3 %.
+#ifdef IMMOCO_DIAG   // compiled into libimmoco_hip_diag.so only
+#define IMMOCO_CB() asm volatile("" ::: "memory")
+// writes that OTHER lanes of the wave read next: a real wait (3 per tile, ~100 cycles each), as in the kernel above
+#define IMMOCO_LDS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// ABL (timing-only ablations, wrong results): 1 = no dW1 chains, 2 = no d enc chains (a third of the MFMAs each),
+// 3 = no weight-gradient flush at the end, 4 = no MFMA at all (loads, LDS traffic, VALU work and stores stay),
+// 5 / 6 = the flush spread over 4 / 16 copies of dW1 / dW2 (2048 / 1024 floats apart: the CALLER must have allocated them -
+// tools/check_pipe_bwd.py does; timing of the atomics' contention only), 7 = prologue and flush only (no tile loop),
+// 8 = as 4 and no activation work either (loads, LDS staging / transposes, stores, flush), 9 = 7 without the atomics,
+// 10 = 7 without the weight-fragment build, 11 = empty kernel (harness offset).
+// ABL = 12 is NOT an ablation: the weight gradients leave the workgroup as plain stores of per-workgroup (dW1) / per-wave (dW2)
+// partial sums into a scratch buffer (dw1 / dw2 point there), and mlp_dw_reduce_kernel sums them in a fixed order - no global
+// atomics, and a deterministic result.
+template <int ACT, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void mlp_bwd64_pipe_kernel(const float* in /* may alias din */, int64_t ps, int64_t ls,
+                                                                int64_t n, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2,
+                                                                const float* __restrict__ dout, float* din,
+                                                                float* __restrict__ dw1, float* __restrict__ dw2,
+                                                                int64_t n_tiles, int64_t dout_plane) {
+  constexpr int HID = 64, NJT = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* aw = reinterpret_cast<float4*>(smem);                  // W1 fragments    [NJT][4][64]
+  float4* awt = aw + NJT * 4 * 64;                               // W1^T fragments  [NJT][4][64]
+  float* w2s = reinterpret_cast<float*>(awt + NJT * 4 * 64);     // [2][HID]
+  float* dos_all = w2s + 2 * HID;                                // per wave 64 floats (epilogue scratch)
+  float* tr_all = dos_all + 4 * 64;                              // per wave three [32][TLD] tiles: dp0', dp1', enc
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  float* dos = dos_all + wave * 64;
+  float* tr0 = tr_all + wave * 3 * 32 * TLD;
+  float* tr1 = tr0 + 32 * TLD;
+  float* te = tr1 + 32 * TLD;
+  if (ABL == 11) return;
+  if (ABL != 10) build_weight_frags<HID>(w1, aw, awt, threadIdx.x);
+  for (int i = threadIdx.x; i < 2 * HID; i += 256) w2s[i] = w2[i];
+  __syncthreads();
+
+  f32x16 dw1t0 = {0.f}, dw1t1 = {0.f};
+  float dw2l[NJT][16][2];
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dw2l[jt][g][0] = dw2l[jt][g][1] = 0.f;
+
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
+  float eb[16];
+  float2 dnx = make_float2(0.f, 0.f);
+  // RAW loads: no arithmetic on the loaded values here.  load_enc_b multiplies every value by the tail mask right after its
+  // load, which makes the wave wait for the "prefetch" on the spot (the ISA of the kernel above shows s_waitcnt vmcnt(16) ...
+  // vmcnt(0) directly behind the 18 loads: the full memory latency of every tile is exposed).  Only dout needs the mask (a
+  // point beyond n then has dpre = 0, so its clamped - finite - encoding contributes nothing), and it is applied one tile
+  // later, where the values are needed anyway.
+  float mnx = 0.f;
+  auto load_tile = [&](int64_t tt) {   // straight into eb (dead after the two pre chains of the current tile)
+    const int64_t q = tt * 32 + r;
+    const int64_t qc = q < n ? q : n - 1;
+    mnx = q < n ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) eb[s] = in[qc * ps + (int64_t)s * ls + h];
+    if (dout_plane) {  // wave-uniform
+      dnx = make_float2(dout[qc], dout[dout_plane + qc]);
+    } else {
+      dnx = *reinterpret_cast<const float2*>(dout + qc * 2);
+    }
+  };
+  // activation work of one hidden tile: h = act(pre), dpre = (W2^T dout) act'(h), per-lane dW2 partial sums
+  auto valu = [&](const f32x16& pre, const int jt, const float2 d, float (&dp)[16], const int a0, const int a1) {
+#pragma unroll
+    for (int a = a0; a < a1; ++a) {
+      const float4 wa = *reinterpret_cast<const float4*>(w2s + jt * 32 + 8 * a + 4 * h);
+      const float4 wb = *reinterpret_cast<const float4*>(w2s + HID + jt * 32 + 8 * a + 4 * h);
+      const float was[4] = {wa.x, wa.y, wa.z, wa.w}, wbs[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (ABL == 8) {   // timing ablation: no activation work
+          dp[4 * a + b] = pre[4 * a + b] + was[b];
+          dw2l[jt][4 * a + b][0] += wbs[b];
+          continue;
+        }
+        const float hh = act_f<ACT>(pre[4 * a + b]);
+        dp[4 * a + b] = fmaf(was[b], d.x, wbs[b] * d.y) * act_d<ACT>(hh);
+        dw2l[jt][4 * a + b][0] = fmaf(hh, d.x, dw2l[jt][4 * a + b][0]);
+        dw2l[jt][4 * a + b][1] = fmaf(hh, d.y, dw2l[jt][4 * a + b][1]);
+      }
+    }
+  };
+  auto denc_chain = [&](const int jt, const float (&dp)[16], f32x16& denc) {   // d enc^T[k][p] += sum_j W1[j][k] dpre[j][p]
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 a = awt[(jt * 4 + g4) * 64 + lane];
+      denc = mfma32(a.x, dp[4 * g4], denc);
+      denc = mfma32(a.y, dp[4 * g4 + 1], denc);
+      denc = mfma32(a.z, dp[4 * g4 + 2], denc);
+      denc = mfma32(a.w, dp[4 * g4 + 3], denc);
+    }
+  };
+  auto dw1_chain = [&](const float* tr, f32x16& acc) {   // dW1^T[k][j] += sum_p enc[p][k] dpre'[p][j]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 qd = *reinterpret_cast<const float4*>(tr + r * TLD + 8 * a + 4 * h);
+      const float4 qe = *reinterpret_cast<const float4*>(te + r * TLD + 8 * a + 4 * h);
+      acc = mfma32(qe.x, qd.x, acc);
+      acc = mfma32(qe.y, qd.y, acc);
+      acc = mfma32(qe.z, qd.z, acc);
+      acc = mfma32(qe.w, qd.w, acc);
+    }
+  };
+
+  constexpr bool NO_LOOP = ABL == 7 || ABL == 9 || ABL == 10;
+  if (!NO_LOOP && wave_id < n_tiles) load_tile(wave_id);
+  for (int64_t t = wave_id; t < (NO_LOOP ? 0 : n_tiles); t += n_waves) {
+    const int64_t p = t * 32 + r;
+    const bool valid = p < n;
+    const float2 d = make_float2(dnx.x * mnx, dnx.y * mnx);
+    // ---- stage the enc tile (rows = feature k = 2s + h, cols = point); earlier readers of `te` (the previous tile's dW1
+    // chains) precede these writes in the wave's in-order LDS queue
+    IMMOCO_CB();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) te[(2 * s + h) * TLD + r] = eb[s];
+    IMMOCO_LDS_DONE();
+    // Six stages of 16 MFMAs; sched_barrier(0) = nothing moves across, so every stage is its own scheduling region, and in
+    // the four mixed ones sched_group_barrier pins "1 MFMA, then 13 VALU instructions" (half a hidden tile's activation work
+    // is ~215 instructions incl. 16 quarter-rate ones: ~76 cycles of VALU per 64-cycle MFMA).
+#define IMMOCO_MIX()                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {   \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  \
+  }                                                     \
+  __builtin_amdgcn_sched_barrier(0)
+    // ---- 1: pre0
+    f32x16 pre0, pre1;
+    if (ABL == 4 || ABL == 8) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { pre0[g] = eb[g]; pre1[g] = eb[15 - g]; }
+    } else {
+      pre0 = pre_tile(aw, 0, lane, eb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2: pre1 | first half of the activation work of pre0
+    if (ABL != 4 && ABL != 8) pre1 = pre_tile(aw, 1, lane, eb);
+    float dp0[16], dp1[16];
+    valu(pre0, 0, d, dp0, 0, 2);
+    IMMOCO_MIX();
+    if (ABL == 12 && t + n_waves < n_tiles) load_tile(t + n_waves);   // eb is dead from here: four stages of latency hiding
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3: d enc chain of hidden tile 0 | second half of pre0's activation work (k-steps 8..15 take dp0[8..15] just in time)
+    f32x16 denc = {0.f};
+    valu(pre0, 0, d, dp0, 2, 4);
+    if (ABL != 2 && ABL != 4 && ABL != 8) denc_chain(0, dp0, denc);
+    IMMOCO_MIX();
+    // ---- 4: dW1 chain of hidden tile 0 (dpre' through the wave's LDS tile) | first half of pre1's activation work
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tr0[drow(g, h) * TLD + r] = dp0[g];
+    IMMOCO_LDS_DONE();
+    if (ABL != 1 && ABL != 4 && ABL != 8) dw1_chain(tr0, dw1t0);
+    valu(pre1, 1, d, dp1, 0, 2);
+    IMMOCO_MIX();
+    // ---- 5: d enc chain of hidden tile 1 | second half of pre1's activation work
+    valu(pre1, 1, d, dp1, 2, 4);
+    if (ABL != 2 && ABL != 4 && ABL != 8) denc_chain(1, dp1, denc);
+    IMMOCO_MIX();
+    // ---- 6: dW1 chain of hidden tile 1 | the next tile's loads (eb is dead since stage 2) and the d enc stores
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tr1[drow(g, h) * TLD + r] = dp1[g];
+    IMMOCO_LDS_DONE();
+    if (ABL != 12 && t + n_waves < n_tiles) load_tile(t + n_waves);
+    if (ABL != 1 && ABL != 4 && ABL != 8) dw1_chain(tr1, dw1t1);
+    if (ABL == 4 || ABL == 8) {   // keep the LDS transposes alive without MFMAs
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        dw1t0[g] += tr0[r * TLD + g + 16 * h] + te[r * TLD + g];
+        dw1t1[g] += tr1[r * TLD + g + 16 * h];
+        denc[g] = dp0[g] + dp1[g];
+      }
+    }
+#undef IMMOCO_MIX
+    if (valid) {   // rows = feature (g&3) + 8(g>>2) + 4h, col = point
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int level = 4 * a + 2 * h;
+        *reinterpret_cast<float2*>(din + p * ps + (int64_t)level * ls) = make_float2(denc[4 * a], denc[4 * a + 1]);
+        *reinterpret_cast<float2*>(din + p * ps + (int64_t)(level + 1) * ls) =
+            make_float2(denc[4 * a + 2], denc[4 * a + 3]);
+      }
+    }
+  }
+  const bool has_tile = wave_id < n_tiles;
+  if (ABL == 3) return;
+  if (ABL == 12) {
+    dw1 += (size_t)blockIdx.x * 2048;
+    dw2 += (size_t)(blockIdx.x * 4 + wave) * 128;
+  }
+  if (ABL == 5 || ABL == 6) {
+    const int c = blockIdx.x & (ABL == 5 ? 3 : 15);
+    dw1 += (size_t)c * 2048;
+    dw2 += (size_t)c * 1024;
+  }
+  // ---- flush (as in mlp_bwd_mfma_kernel<64, ACT>; tile stride 3 per wave here)
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt) {
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tr0[r * TLD + drow(g, h)] = jt == 0 ? dw1t0[g] : dw1t1[g];  // [hidden r][feature k]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = (4 * wave + k) * 64 + lane;
+      const int off = (idx >> 5) * TLD + (idx & 31);
+      const float v = (tr_all[off] + tr_all[3 * 32 * TLD + off]) + (tr_all[6 * 32 * TLD + off] + tr_all[9 * 32 * TLD + off]);
+      if (ABL == 9 || ABL == 12) dw1[(size_t)jt * 1024 + idx] = v;
+      else unsafeAtomicAdd(dw1 + (size_t)jt * 1024 + idx, v);
+    }
+    if (!has_tile && ABL != 12) continue;   // (12: a wave without tiles stores its zeros)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float v0 = dw2l[jt][g][0], v1 = dw2l[jt][g][1];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        v0 += __shfl_xor(v0, m, 64);
+        v1 += __shfl_xor(v1, m, 64);
+      }
+      if (r == 0) {
+        dos[drow(g, h)] = v0;
+        dos[32 + drow(g, h)] = v1;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (h == 0) {
+      if (ABL == 9 || ABL == 12) {
+        dw2[jt * 32 + r] = dos[r];
+        dw2[HID + jt * 32 + r] = dos[32 + r];
+      } else {
+        unsafeAtomicAdd(dw2 + jt * 32 + r, dos[r]);
+        unsafeAtomicAdd(dw2 + HID + jt * 32 + r, dos[32 + r]);
+      }
+    }
+  }
+}
+
+// dw1[o] += sum_b p1[b][o] (o < 2048, b < nb), dw2[o] += sum_w p2[w][o] (o < 128, w < 4 nb).  Workgroups 0..127: 16 outputs
+// of dW1 x 16 partial groups; workgroups 128..159: 4 outputs of dW2 x 64 partial groups (four times as many partials per
+// output).  Every thread sums its group's partials in index order, the group sums are added in group order: deterministic.
+__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int nb,
+                                                            float* __restrict__ dw1, float* __restrict__ dw2) {
+  __shared__ float red[64][17];
+  const bool first = blockIdx.x < 128;
+  const int no = first ? 16 : 4, ng = first ? 16 : 64;                 // outputs per workgroup, partial groups
+  const int ol = threadIdx.x % no, q = threadIdx.x / no;
+  const int o = first ? blockIdx.x * 16 + ol : (blockIdx.x - 128) * 4 + ol;
+  const float* src = first ? p1 + o : p2 + o;
+  const int stride = first ? 2048 : 128, count = first ? nb : 4 * nb;
+  float s0 = 0.f;
+#pragma unroll 8
+  for (int b = q; b < count; b += ng) s0 += src[(size_t)b * stride];
+  red[q][ol] = s0;
+  __syncthreads();
+  if (q == 0) {
+    float t = 0.f;
+    for (int k = 0; k < ng; ++k) t += red[k][ol];
+    if (first) dw1[o] += t;
+    else dw2[o] += t;
+  }
+}
+#undef IMMOCO_CB
+#undef IMMOCO_LDS_DONE
+#endif  // IMMOCO_DIAG
 
 // ---------------------------------------------------------------------------------------------
 // Split backward of the WIDE net (round 4): two kernels that each fit BESIDE the motion grid's encode backward
@@ -679,6 +979,16 @@ static int launch_bwd_t(const float* in, int64_t ps, int64_t ls, int64_t n, cons
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     attr_set = true;
   }
+#ifdef IMMOCO_DIAG
+  static const bool raw = [] { const char* e = immoco_diag_env("IMMOCO_MLP_RAWLOAD"); return e && atoi(e) != 0; }();
+  if (raw && HID == 64) {
+    IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_mfma_kernel<HID, ACT, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    mlp_bwd_mfma_kernel<HID, ACT, true><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles, dout_plane);
+    IMMOCO_LAUNCH_CHECK();
+    return IMMOCO_OK;
+  }
+#endif
   mlp_bwd_mfma_kernel<HID, ACT><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles, dout_plane);
   IMMOCO_LAUNCH_CHECK();
   return IMMOCO_OK;
@@ -689,6 +999,57 @@ int launch_mlp_bwd_mfma(const immoco_mlp_cfg& cfg, const float* in, int64_t ps, 
                         hipStream_t st, int64_t dout_plane) {
   if (n == 0) return IMMOCO_OK;
   IMMOCO_REQUIRE((ps % 2) == 0 && (ls % 2) == 0, "mlp input strides must be even");
+#ifdef IMMOCO_DIAG
+  // diagnostics build only: IMMOCO_MLP_BWD64=pipe selects the software-pipelined narrow backward (experiment, see above)
+  static const int pipe64 = [] {
+    const char* e = immoco_diag_env("IMMOCO_MLP_BWD64");
+    return !e ? 0 : strcmp(e, "pipe") == 0 ? 1 : strcmp(e, "pipe_nodw1") == 0 ? 2 : strcmp(e, "pipe_nodenc") == 0 ? 3
+           : strcmp(e, "pipe_noflush") == 0 ? 4 : strcmp(e, "pipe_nomfma") == 0 ? 5
+           : strcmp(e, "pipe_spread4") == 0 ? 6 : strcmp(e, "pipe_spread16") == 0 ? 7
+           : strcmp(e, "pipe_fixed") == 0 ? 8 : strcmp(e, "pipe_memonly") == 0 ? 9
+           : strcmp(e, "pipe_fixed_noatomic") == 0 ? 10 : strcmp(e, "pipe_fixed_nobuild") == 0 ? 11 : strcmp(e, "pipe_empty") == 0 ? 12
+           : strcmp(e, "pipe_partials") == 0 ? 13 : 0;
+  }();
+  if (pipe64 && cfg.n_hidden == 64) {
+    const int64_t n_tiles = cdiv(n, 32);
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv(n_tiles, 4), 512);
+    const size_t sm = (size_t)2 * 4 * 64 * 16 * 2 + (size_t)2 * 64 * 4 + 4 * 64 * 4 + (size_t)4 * 3 * 32 * TLD * 4;
+#define IMMOCO_PIPE(A, B)                                                                                              \
+  do {                                                                                                                 \
+    IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd64_pipe_kernel<A, B>),                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));                        \
+    mlp_bwd64_pipe_kernel<A, B><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, n_tiles, dout_plane); \
+  } while (0)
+    if (pipe64 == 13 && cfg.activation == IMMOCO_ACT_TANH) {   // partial sums + fixed-order reduction instead of atomics
+      static float* scratch = nullptr;   // [512][2048] + [2048][128] floats (diagnostics build: never freed)
+      if (!scratch) IMMOCO_CHECK_HIP(hipMalloc((void**)&scratch, ((size_t)512 * 2048 + (size_t)2048 * 128) * sizeof(float)));
+      float* p1 = scratch;
+      float* p2 = scratch + (size_t)512 * 2048;
+      IMMOCO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd64_pipe_kernel<IMMOCO_ACT_TANH, 12>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+      mlp_bwd64_pipe_kernel<IMMOCO_ACT_TANH, 12><<<grid, 256, sm, st>>>(in, ps, ls, n, w1, w2, dout, din, p1, p2, n_tiles, dout_plane);
+      mlp_dw_reduce_kernel<<<128 + 32, 256, 0, st>>>(p1, p2, (int)grid, dw1, dw2);
+      IMMOCO_LAUNCH_CHECK();
+      return IMMOCO_OK;
+    }
+    if (cfg.activation != IMMOCO_ACT_TANH) IMMOCO_PIPE(IMMOCO_ACT_RELU, 0);
+    else if (pipe64 == 2) IMMOCO_PIPE(IMMOCO_ACT_TANH, 1);
+    else if (pipe64 == 3) IMMOCO_PIPE(IMMOCO_ACT_TANH, 2);
+    else if (pipe64 == 4) IMMOCO_PIPE(IMMOCO_ACT_TANH, 3);
+    else if (pipe64 == 5) IMMOCO_PIPE(IMMOCO_ACT_TANH, 4);
+    else if (pipe64 == 6) IMMOCO_PIPE(IMMOCO_ACT_TANH, 5);
+    else if (pipe64 == 7) IMMOCO_PIPE(IMMOCO_ACT_TANH, 6);
+    else if (pipe64 == 8) IMMOCO_PIPE(IMMOCO_ACT_TANH, 7);
+    else if (pipe64 == 9) IMMOCO_PIPE(IMMOCO_ACT_TANH, 8);
+    else if (pipe64 == 10) IMMOCO_PIPE(IMMOCO_ACT_TANH, 9);
+    else if (pipe64 == 11) IMMOCO_PIPE(IMMOCO_ACT_TANH, 10);
+    else if (pipe64 == 12) IMMOCO_PIPE(IMMOCO_ACT_TANH, 11);
+    else IMMOCO_PIPE(IMMOCO_ACT_TANH, 0);
+#undef IMMOCO_PIPE
+    IMMOCO_LAUNCH_CHECK();
+    return IMMOCO_OK;
+  }
+#endif
   if (cfg.n_hidden == 64 && cfg.activation == IMMOCO_ACT_TANH)
     return launch_bwd_t<64, IMMOCO_ACT_TANH>(in, ps, ls, n, w1, w2, dout, din, dw1, dw2, st, dout_plane);
   if (cfg.n_hidden == 64)
